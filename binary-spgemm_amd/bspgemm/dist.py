@@ -1,0 +1,90 @@
+"""Multi-GPU layer: one process per GPU, B replicated, contiguous A-row shards cut at equal work,
+C.row_ptr stitched with an all-gather -- the job of SpGEMM_mpi (reference
+final/SpGEMM_mpi_omp.c:155-225), whose MPI_Reduce / MPI_Gather / MPI_Gatherv + serial rebase
+(:178-223) become one collective on int64 row_ptr shards plus a device-side rebase.  col_idx
+stays sharded on the GPUs (the reference ships it to rank 0 with MPI_Gatherv, :203).
+
+The collective runs through torch.distributed: backend "nccl" is RCCL over xGMI on the GPU
+box; backend "gloo" runs the same code on CPU tensors (tests/test_dist_gloo.py, world_size 2).
+Nothing here computes a product: the shard multiply is bspgemm.Context.multiply (HIP).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PER_ROW_COST = 32   # products-equivalent charged per row when cutting shards (matches api.hip)
+
+
+def shard_bounds(work_prefix, parts, per_row=PER_ROW_COST):
+    """Cut rows [0,R) into `parts` contiguous shards of equal cost = products + per_row*rows.
+
+    Same rule as bspgemm_partition_rows (csrc/api.hip).  The reference cuts An/numtasks equal
+    row counts (final/SpGEMM_mpi_omp.c:165), which is up to 3x unbalanced on skewed inputs
+    (SURVEY.md 8e).
+    """
+    work_prefix = np.asarray(work_prefix, dtype=np.int64)
+    R = work_prefix.size - 1
+    cost = work_prefix + per_row * np.arange(R + 1, dtype=np.int64)
+    total = int(cost[R])
+    bounds = np.zeros(parts + 1, dtype=np.int32)
+    for p in range(1, parts):
+        target = total // parts * p
+        bounds[p] = int(np.searchsorted(cost, target, side="left"))
+    bounds[parts] = R
+    return np.maximum.accumulate(bounds).astype(np.int32)
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_tensor(ptr, n, dtype, device):
+    """torch tensor aliasing `n` elements at device pointer `ptr` (no copy)."""
+    typestr = {torch.int64: "<i8", torch.int32: "<i4"}[dtype]
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
+
+
+def stitch_row_ptr(local_row_ptr, bounds, group=None):
+    """All-gather the shard row_ptrs and rebase them into the global C.row_ptr on every rank.
+
+    local_row_ptr : int64 tensor [rows_r + 1], slice-local (starts at 0) -- on the GPU for
+                    backend nccl, on the CPU for gloo.
+    bounds        : int array [world+1], the shard row bounds every rank used.
+    Returns (global_row_ptr int64 [R+1] on the same device, shard_nnz int64 [world] on it too).
+    One collective: shards are padded to the longest (equal-work cuts make them near-equal) and
+    the shard total rides in the pad slot, so sizes and row_ptrs travel together.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bounds = np.asarray(bounds, dtype=np.int64)
+    rows = bounds[1:] - bounds[:-1]
+    assert local_row_ptr.numel() == rows[rank] + 1, "local row_ptr does not match bounds[rank]"
+    width = int(rows.max()) + 1
+    send = torch.zeros(width, dtype=torch.int64, device=local_row_ptr.device)
+    send[: rows[rank]] = local_row_ptr[: rows[rank]]
+    send[width - 1] = local_row_ptr[rows[rank]]                 # shard nnz in the last slot
+    recv = torch.empty(world * width, dtype=torch.int64, device=local_row_ptr.device)
+    if local_row_ptr.is_cuda and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        _all_gather_list(recv, send, world, group)
+    recv = recv.view(world, width)
+    shard_nnz = recv[:, width - 1].clone()
+    base = torch.cumsum(shard_nnz, 0) - shard_nnz               # exclusive prefix = shard bases
+    out = torch.empty(int(bounds[-1]) + 1, dtype=torch.int64, device=local_row_ptr.device)
+    for r in range(world):
+        out[int(bounds[r]): int(bounds[r + 1])] = recv[r, : int(rows[r])] + base[r]
+    out[int(bounds[-1])] = shard_nnz.sum()
+    return out, shard_nnz
+
+
+def _all_gather_list(recv, send, world, group):
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    recv.copy_(torch.cat(parts))

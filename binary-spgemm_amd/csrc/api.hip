@@ -1,0 +1,680 @@
+// api.hip -- the C ABI of include/bspgemm.h over the HIP kernels (native handle API, int32
+// drop-ins, RCCL stitch).  No CPU compute path exists in this library: without a gfx950 device
+// every compute entry point fails with BSPGEMM_ERR_NO_DEVICE.
+#include "../../include/bspgemm.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace bsp;
+
+// ------------------------------------------------------------------ errors ---------------
+static thread_local char g_err[512] = "";
+
+static bspgemm_status fail(bspgemm_status st, const char *what, const char *file, int line)
+{
+    snprintf(g_err, sizeof g_err, "%s (%s:%d)", what, file, line);
+    return st;
+}
+#define FAIL(st, what) fail((st), (what), __FILE__, __LINE__)
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                     __FILE__, __LINE__);                                                  \
+            return (e_ == hipErrorOutOfMemory) ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP;      \
+        }                                                                                  \
+    } while (0)
+#define NCCLCHK(call)                                                                      \
+    do {                                                                                   \
+        ncclResult_t r_ = (call);                                                          \
+        if (r_ != ncclSuccess) {                                                           \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, ncclGetErrorString(r_), \
+                     __FILE__, __LINE__);                                                  \
+            return BSPGEMM_ERR_COMM;                                                       \
+        }                                                                                  \
+    } while (0)
+
+extern "C" const char *bspgemm_last_error(void) { return g_err; }
+
+extern "C" const char *bspgemm_status_string(bspgemm_status s)
+{
+    switch (s) {
+    case BSPGEMM_OK: return "ok";
+    case BSPGEMM_ERR_INVALID: return "invalid argument";
+    case BSPGEMM_ERR_ALLOC: return "allocation failed";
+    case BSPGEMM_ERR_HIP: return "HIP runtime error";
+    case BSPGEMM_ERR_NO_DEVICE: return "no gfx950 device (this library has no CPU fallback)";
+    case BSPGEMM_ERR_OVERFLOW: return "result exceeds the int32 drop-in interface";
+    case BSPGEMM_ERR_IO: return "file I/O error";
+    case BSPGEMM_ERR_FORMAT: return "Matrix Market format rejected";
+    case BSPGEMM_ERR_COMM: return "RCCL error";
+    }
+    return "unknown status";
+}
+
+// ------------------------------------------------------------------ objects --------------
+struct HostScalars {
+    long long totalF;
+    long long nnzC;
+    int bin_count[kNumBins];
+    int a_lo, a_hi;
+};
+
+struct bspgemm_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // per-row workspace (capacity rows_cap rows)
+    size_t rows_cap = 0;
+    long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr;
+    int *cnt = nullptr, *bin_rows = nullptr, *bin_count = nullptr;
+    // upper-bound placed rows
+    size_t tmp_cap = 0;
+    int *tmp = nullptr;
+    HostScalars *h = nullptr;          // pinned
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_bin[kNumBins + 1] = {};   // brackets of the per-class numeric launches
+    bspgemm_stats stats;
+    bool stats_valid = false;
+};
+
+struct bspgemm_matrix {
+    bspgemm_context *ctx;
+    int rows, cols;
+    long long nnz;
+    int *d_row_ptr, *d_col_idx;
+    bool owned;
+};
+
+struct bspgemm_result {
+    bspgemm_context *ctx;
+    int rows;
+    long long nnz;
+    long long *d_row_ptr;
+    int *d_col_idx;
+};
+
+static bspgemm_status use_device(bspgemm_context *ctx)
+{
+    HIPCHK(hipSetDevice(ctx->device));
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
+{
+    if (!out) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return FAIL(BSPGEMM_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return FAIL(BSPGEMM_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof g_err, "device %d is %s; libbspgemm carries gfx950 code only", device,
+                 prop.gcnArchName);
+        return BSPGEMM_ERR_NO_DEVICE;
+    }
+    bspgemm_context *ctx = new (std::nothrow) bspgemm_context();
+    if (!ctx) return FAIL(BSPGEMM_ERR_ALLOC, "context");
+    ctx->device = device;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
+    for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    for (auto &e : ctx->ev_bin) HIPCHK(hipEventCreate(&e));
+    // keep freed result buffers in the pool: results are allocated per multiply, like the
+    // reference's per-call malloc of Ccol (final/SpGEMM_mpi_omp.c:115)
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t thr = UINT64_MAX;
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    *out = ctx;
+    return BSPGEMM_OK;
+}
+
+extern "C" void bspgemm_destroy(bspgemm_context *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
+    hipFree(ctx->cnt); hipFree(ctx->bin_rows); hipFree(ctx->bin_count); hipFree(ctx->tmp);
+    if (ctx->h) hipHostFree(ctx->h);
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    for (auto &e : ctx->ev_bin) if (e) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" bspgemm_status bspgemm_set_stream(bspgemm_context *ctx, void *hip_stream)
+{
+    if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (hip_stream) {
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else if (!ctx->own_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_synchronize(bspgemm_context *ctx)
+{
+    if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BSPGEMM_OK;
+}
+
+// ------------------------------------------------------------------ operands -------------
+extern "C" bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, int cols,
+                                                const int *row_ptr, const int *col_idx,
+                                                bspgemm_matrix **out)
+{
+    if (!ctx || !out || !row_ptr || rows < 0 || cols < 0) return FAIL(BSPGEMM_ERR_INVALID, "matrix_upload");
+    *out = nullptr;
+    const long long base = row_ptr[0];
+    const long long nnz = (long long)row_ptr[rows] - base;
+    if (nnz < 0 || (nnz > 0 && !col_idx)) return FAIL(BSPGEMM_ERR_INVALID, "row_ptr not ascending / col_idx NULL");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    bspgemm_matrix *m = new (std::nothrow) bspgemm_matrix{ctx, rows, cols, nnz, nullptr, nullptr, true};
+    if (!m) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
+    // +1 int of slack on col_idx so an empty matrix still has a valid pointer
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)rows + 1) * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)nnz + 1) * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(m->d_row_ptr, row_ptr, ((size_t)rows + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (nnz > 0)
+        HIPCHK(hipMemcpyAsync(m->d_col_idx, col_idx + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    launch_rebase_i32(m->d_row_ptr, rows + 1, (int)base, ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_matrix_wrap_device(bspgemm_context *ctx, int rows, int cols, int64_t nnz,
+                                                     const int *d_row_ptr, const int *d_col_idx,
+                                                     bspgemm_matrix **out)
+{
+    if (!ctx || !out || !d_row_ptr || rows < 0 || cols < 0 || nnz < 0) return FAIL(BSPGEMM_ERR_INVALID, "matrix_wrap_device");
+    bspgemm_matrix *m = new (std::nothrow) bspgemm_matrix{ctx, rows, cols, (long long)nnz,
+                                                          const_cast<int *>(d_row_ptr),
+                                                          const_cast<int *>(d_col_idx), false};
+    if (!m) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
+    *out = m;
+    return BSPGEMM_OK;
+}
+
+extern "C" void bspgemm_matrix_free(bspgemm_matrix *m)
+{
+    if (!m) return;
+    if (m->owned) {
+        hipSetDevice(m->ctx->device);
+        hipFree(m->d_row_ptr);
+        hipFree(m->d_col_idx);
+    }
+    delete m;
+}
+extern "C" int bspgemm_matrix_rows(const bspgemm_matrix *m) { return m ? m->rows : 0; }
+extern "C" int bspgemm_matrix_cols(const bspgemm_matrix *m) { return m ? m->cols : 0; }
+extern "C" int64_t bspgemm_matrix_nnz(const bspgemm_matrix *m) { return m ? m->nnz : 0; }
+
+// ------------------------------------------------------------------ workspace ------------
+static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
+{
+    if (rows <= ctx->rows_cap) return BSPGEMM_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_rows);
+    ctx->F = ctx->Fprefix = ctx->partials = nullptr;
+    ctx->cnt = ctx->bin_rows = nullptr;
+    ctx->rows_cap = 0;
+    const size_t cap = rows + rows / 8 + 64;
+    const size_t tiles = cap / 2048 + 2;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->F), cap * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fprefix), (cap + 1) * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->partials), (tiles + 1) * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->cnt), cap * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_rows), (size_t)kNumBins * cap * sizeof(int)));
+    ctx->rows_cap = cap;
+    return BSPGEMM_OK;
+}
+
+static bspgemm_status ensure_tmp(bspgemm_context *ctx, size_t ints)
+{
+    if (ints <= ctx->tmp_cap) return BSPGEMM_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->tmp);
+    ctx->tmp = nullptr;
+    ctx->tmp_cap = 0;
+    const size_t cap = ints + ints / 16 + 1024;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tmp), cap * sizeof(int)));
+    ctx->tmp_cap = cap;
+    return BSPGEMM_OK;
+}
+
+// ------------------------------------------------------------------ multiply -------------
+static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                     int row_begin, int row_end)
+{
+    if (!ctx || !A || !B) return FAIL(BSPGEMM_ERR_INVALID, "NULL operand");
+    if (A->ctx != ctx || B->ctx != ctx) return FAIL(BSPGEMM_ERR_INVALID, "operand belongs to another context");
+    if (row_begin < 0 || row_end < row_begin || row_end > A->rows) return FAIL(BSPGEMM_ERR_INVALID, "row range");
+    if (B->rows < A->cols) return FAIL(BSPGEMM_ERR_INVALID, "B has fewer rows than A has columns");
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                           const bspgemm_matrix *B, int row_begin, int row_end,
+                                           bspgemm_result **out)
+{
+    if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
+    *out = nullptr;
+    if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int R = row_end - row_begin;
+    hipStream_t s = ctx->stream;
+    if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+
+    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr};
+    if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
+    auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
+#define HIPCHK_C(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                     __FILE__, __LINE__);                                                  \
+            return bail((e_ == hipErrorOutOfMemory) ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP);\
+        }                                                                                  \
+    } while (0)
+
+    HIPCHK_C(hipEventRecord(ctx->ev[0], s));
+    HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_row_ptr), ((size_t)R + 1) * sizeof(long long), s));
+
+    // ---- symbolic: per-row products, their prefix, capacity bins -----------------------
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, s);
+    launch_scan_and_bin(ctx->F, R, row_begin, ctx->Fprefix, ctx->partials, ctx->bin_rows, ctx->bin_count,
+                        ctx->cnt, s);
+    HostScalars *h = ctx->h;
+    HIPCHK_C(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_C(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_C(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_C(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_C(hipEventRecord(ctx->ev[1], s));
+    HIPCHK_C(hipStreamSynchronize(s));
+    const long long totalF = R > 0 ? h->totalF : 0;
+    if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
+    if (bspgemm_status st = ensure_tmp(ctx, (size_t)totalF + 1)) return bail(st);
+
+    // ---- numeric: accumulate + emit every row at its upper-bound offset -----------------
+    const int levels = levels_for_cols(B->cols);
+    for (int b = 1; b <= kWaveBins; b++) {
+        HIPCHK_C(hipEventRecord(ctx->ev_bin[b], s));
+        launch_wave_rows(b, levels, A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols,
+                         ctx->bin_rows + (size_t)b * R, h->bin_count[b], row_begin, ctx->Fprefix,
+                         ctx->tmp, ctx->cnt, s);
+    }
+    HIPCHK_C(hipEventRecord(ctx->ev_bin[7], s));
+    HIPCHK_C(launch_dense_rows(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols,
+                               ctx->bin_rows + (size_t)7 * R, h->bin_count[7], row_begin, ctx->Fprefix,
+                               ctx->tmp, ctx->cnt, s));
+    HIPCHK_C(hipGetLastError());
+    HIPCHK_C(hipEventRecord(ctx->ev_bin[8], s));
+    HIPCHK_C(hipEventRecord(ctx->ev[2], s));
+
+    // ---- stitch: counts -> C.row_ptr, rows squeezed into the exact-size col_idx ---------
+    launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, s);
+    HIPCHK_C(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_C(hipStreamSynchronize(s));
+    C->nnz = h->nnzC;
+    HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int), s));
+    launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->d_col_idx, s);
+    launch_compact_big(ctx->tmp, ctx->Fprefix, C->d_row_ptr, ctx->bin_rows + (size_t)7 * R, h->bin_count[7],
+                       row_begin, C->d_col_idx, s);
+    HIPCHK_C(hipGetLastError());
+    HIPCHK_C(hipEventRecord(ctx->ev[3], s));
+    HIPCHK_C(hipStreamSynchronize(s));
+#undef HIPCHK_C
+
+    bspgemm_stats &st = ctx->stats;
+    memset(&st, 0, sizeof st);
+    st.rows = R;
+    st.nnz_a = R > 0 ? (long long)h->a_hi - h->a_lo : 0;
+    st.products = totalF;
+    st.nnz_c = C->nnz;
+    st.bytes_alg = 4ll * (R + 1) + 12ll * st.nnz_a + 4ll * totalF + 4ll * C->nnz + 8ll * (R + 1);
+    for (int b = 0; b < kNumBins; b++) st.rows_per_bin[b] = h->bin_count[b];
+    hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[3]);
+    hipEventElapsedTime(&st.ms_symbolic, ctx->ev[0], ctx->ev[1]);
+    hipEventElapsedTime(&st.ms_numeric, ctx->ev[1], ctx->ev[2]);
+    hipEventElapsedTime(&st.ms_stitch, ctx->ev[2], ctx->ev[3]);
+    for (int b = 1; b < kNumBins; b++)
+        if (h->bin_count[b] > 0) hipEventElapsedTime(&st.ms_bin[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]);
+    ctx->stats_valid = true;
+    *out = C;
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *, const bspgemm_matrix *,
+                                                  const bspgemm_matrix *, const bspgemm_matrix *, int, int,
+                                                  bspgemm_result **out)
+{
+    if (out) *out = nullptr;
+    return FAIL(BSPGEMM_ERR_INVALID, "masked product: not built yet (SURVEY.md 8f row f3)");
+}
+
+extern "C" int bspgemm_result_rows(const bspgemm_result *C) { return C ? C->rows : 0; }
+extern "C" int64_t bspgemm_result_nnz(const bspgemm_result *C) { return C ? C->nnz : 0; }
+extern "C" const int64_t *bspgemm_result_row_ptr_device(const bspgemm_result *C)
+{
+    return C ? reinterpret_cast<const int64_t *>(C->d_row_ptr) : nullptr;
+}
+extern "C" const int *bspgemm_result_col_idx_device(const bspgemm_result *C) { return C ? C->d_col_idx : nullptr; }
+
+extern "C" bspgemm_status bspgemm_result_download(bspgemm_context *ctx, const bspgemm_result *C,
+                                                  int64_t *row_ptr, int *col_idx)
+{
+    if (!ctx || !C) return FAIL(BSPGEMM_ERR_INVALID, "result_download");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    if (row_ptr)
+        HIPCHK(hipMemcpyAsync(row_ptr, C->d_row_ptr, ((size_t)C->rows + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (col_idx && C->nnz > 0)
+        HIPCHK(hipMemcpyAsync(col_idx, C->d_col_idx, (size_t)C->nnz * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BSPGEMM_OK;
+}
+
+extern "C" void bspgemm_result_free(bspgemm_result *C)
+{
+    if (!C) return;
+    hipSetDevice(C->ctx->device);
+    if (C->d_row_ptr) hipFreeAsync(C->d_row_ptr, C->ctx->stream);
+    if (C->d_col_idx) hipFreeAsync(C->d_col_idx, C->ctx->stream);
+    delete C;
+}
+
+extern "C" bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out)
+{
+    if (!ctx || !out || !ctx->stats_valid) return FAIL(BSPGEMM_ERR_INVALID, "no multiply has run on this context");
+    *out = ctx->stats;
+    return BSPGEMM_OK;
+}
+
+// ------------------------------------------------------------------ sharding helper ------
+extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                                  const bspgemm_matrix *B, int64_t *prefix_host)
+{
+    if (!prefix_host) return FAIL(BSPGEMM_ERR_INVALID, "prefix_host is NULL");
+    if (bspgemm_status st = check_operands(ctx, A, B, 0, A ? A->rows : 0)) return st;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int R = A->rows;
+    if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, 0, R, ctx->F, ctx->stream);
+    launch_scan_and_bin(ctx->F, R, 0, ctx->Fprefix, ctx->partials, ctx->bin_rows, ctx->bin_count, ctx->cnt,
+                        ctx->stream);
+    HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_partition_rows(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                                 const bspgemm_matrix *B, int parts, int *bounds)
+{
+    if (!bounds || parts <= 0 || !A) return FAIL(BSPGEMM_ERR_INVALID, "partition_rows");
+    const int R = A->rows;
+    int64_t *prefix = static_cast<int64_t *>(malloc(((size_t)R + 1) * sizeof(int64_t)));
+    if (!prefix) return FAIL(BSPGEMM_ERR_ALLOC, "prefix");
+    bspgemm_status st = bspgemm_row_work_prefix(ctx, A, B, prefix);
+    if (st == BSPGEMM_OK) {
+        // cost of a row = its products + a constant for the per-row overhead
+        const long long per_row = 32;
+        const long long total = prefix[R] + per_row * R;
+        bounds[0] = 0;
+        int r = 0;
+        for (int p = 1; p < parts; p++) {
+            const long long target = total / parts * p;
+            while (r < R && prefix[r] + per_row * r < target) r++;
+            bounds[p] = r;
+        }
+        bounds[parts] = R;
+    }
+    free(prefix);
+    return st;
+}
+
+// ------------------------------------------------------------------ int32 drop-ins -------
+static std::mutex g_dropin_mu;
+static bspgemm_context *g_dropin_ctx = nullptr;
+static int g_dropin_device = -1;
+
+extern "C" int bspgemm_dropin_set_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_dropin_mu);
+    if (g_dropin_ctx && g_dropin_device != device) {
+        bspgemm_destroy(g_dropin_ctx);
+        g_dropin_ctx = nullptr;
+    }
+    g_dropin_device = device;
+    return BSPGEMM_OK;
+}
+
+static bspgemm_status dropin_ctx(bspgemm_context **out)
+{
+    if (!g_dropin_ctx) {
+        int dev = g_dropin_device;
+        if (dev < 0) {
+            const char *e = getenv("BSPGEMM_DEVICE");
+            dev = e ? atoi(e) : 0;
+        }
+        bspgemm_status st = bspgemm_create(dev, &g_dropin_ctx);
+        if (st) return st;
+        g_dropin_device = dev;
+    }
+    *out = g_dropin_ctx;
+    return BSPGEMM_OK;
+}
+
+static int dropin_fail(const char *fn, bspgemm_status st)
+{
+    fprintf(stderr, "%s: %s: %s\n", fn, bspgemm_status_string(st), bspgemm_last_error());
+    return (int)st;
+}
+
+// Shared body: C rows [r0,r1) of A*B with host int32 arrays in the reference's conventions.
+// mode 0: *Ccol = malloc(nnz) (SpGEMM_omp :115)   mode 1: grow caller's buffer (bigslice :28-31)
+// mode 2: caller's buffer is exact (SpGEMM_mat)
+static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r1,
+                                 const int *Bcol, const int *Brow, int Bm,
+                                 int **Ccol, int *Crow, int *Csize, int mode)
+{
+    if (!Acol || !Arow || !Bcol || !Brow || !Crow || !Ccol || r0 < 0 || r1 < r0 || Bm < 0)
+        return FAIL(BSPGEMM_ERR_INVALID, "drop-in arguments");
+    std::lock_guard<std::mutex> lk(g_dropin_mu);
+    bspgemm_context *ctx;
+    if (bspgemm_status st = dropin_ctx(&ctx)) return st;
+    const int rows = r1 - r0;
+    // B's row count is implicit in the reference (never passed): 1 + the largest column of A used
+    int brows = 0;
+    for (int jj = Arow[r0]; jj < Arow[r1]; jj++) if (Acol[jj] >= brows) brows = Acol[jj] + 1;
+    bspgemm_matrix *A = nullptr, *B = nullptr;
+    bspgemm_result *C = nullptr;
+    bspgemm_status st = bspgemm_matrix_upload(ctx, rows, brows, Arow + r0, Acol, &A);
+    if (!st) st = bspgemm_matrix_upload(ctx, brows, Bm, Brow, Bcol, &B);
+    if (!st) st = bspgemm_multiply(ctx, A, B, 0, rows, &C);
+    if (!st) {
+        const long long nnz = bspgemm_result_nnz(C);
+        if (nnz > INT_MAX) {
+            st = FAIL(BSPGEMM_ERR_OVERFLOW, "nnz(C) > INT_MAX: use the int64 handle API");
+        } else {
+            int *dst = nullptr;
+            if (mode == 0) {
+                dst = static_cast<int *>(malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int)));
+            } else if (mode == 1) {
+                dst = *Ccol;
+                if (!dst || !Csize || *Csize < nnz) {
+                    dst = static_cast<int *>(realloc(*Ccol, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int)));
+                    if (dst && Csize) *Csize = (int)(nnz > 0 ? nnz : 1);
+                }
+            } else {
+                dst = *Ccol;
+            }
+            int64_t *rp64 = static_cast<int64_t *>(malloc(((size_t)rows + 1) * sizeof(int64_t)));
+            if (!dst || !rp64) {
+                st = FAIL(BSPGEMM_ERR_ALLOC, "host result");
+                if (mode == 0) free(dst);
+            } else {
+                st = bspgemm_result_download(ctx, C, rp64, dst);
+                if (!st) {
+                    for (int i = 0; i <= rows; i++) Crow[i] = (int)rp64[i];
+                    *Ccol = dst;
+                } else if (mode == 0) {
+                    free(dst);
+                }
+            }
+            free(rp64);
+        }
+    }
+    bspgemm_result_free(C);
+    bspgemm_matrix_free(A);
+    bspgemm_matrix_free(B);
+    return st;
+}
+
+extern "C" int SpGEMM_hip(int *Acol, int *Arow, int An, int *Bcol, int *Brow, int Bm,
+                          int **Ccol, int *Crow, int tBlock)
+{
+    (void)tBlock;
+    if (Ccol) *Ccol = nullptr;
+    bspgemm_status st = dropin_run(Acol, Arow, 0, An, Bcol, Brow, Bm, Ccol, Crow, nullptr, 0);
+    return st ? dropin_fail("SpGEMM_hip", st) : 0;
+}
+
+extern "C" int SpGEMM_hip_bigslice(int *Acol, int *Arow, int An, int *Bcol, int *Brow, int Bm,
+                                   int **Ccol, int *Crow, int *Csize, int start_row, int end_row)
+{
+    (void)An;
+    bspgemm_status st = dropin_run(Acol, Arow, start_row, end_row, Bcol, Brow, Bm, Ccol, Crow, Csize, 1);
+    return st ? dropin_fail("SpGEMM_hip_bigslice", st) : 0;
+}
+
+extern "C" int SpGEMM_hip_mat(int *Acol, int *Arow, int An, int *Bcol, int *Brow, int Bm,
+                              int *Ccol, int *Crow)
+{
+    int *p = Ccol;
+    bspgemm_status st = dropin_run(Acol, Arow, 0, An, Bcol, Brow, Bm, &p, Crow, nullptr, 2);
+    return st ? dropin_fail("SpGEMM_hip_mat", st) : 0;
+}
+
+extern "C" int SpGEMM_hip_masked(int *, int *, int, int *, int *, int, int *, int *, int **Ccol, int *, int *)
+{
+    if (Ccol) *Ccol = nullptr;
+    return dropin_fail("SpGEMM_hip_masked", FAIL(BSPGEMM_ERR_INVALID, "masked product: not built yet"));
+}
+
+// ------------------------------------------------------------------ multi-GPU stitch -----
+struct bspgemm_comm {
+    bspgemm_context *ctx;
+    ncclComm_t comm;
+    int rank, nranks;
+    long long *d_nnz;      // nranks
+    int *d_bounds;         // nranks+1
+};
+
+extern "C" bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == BSPGEMM_UNIQUE_ID_BYTES, "RCCL unique id size");
+    if (!id) return FAIL(BSPGEMM_ERR_INVALID, "id is NULL");
+    ncclUniqueId u;
+    NCCLCHK(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[BSPGEMM_UNIQUE_ID_BYTES],
+                                              int rank, int nranks, bspgemm_comm **out)
+{
+    if (!ctx || !id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return FAIL(BSPGEMM_ERR_INVALID, "comm_create");
+    *out = nullptr;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    bspgemm_comm *c = new (std::nothrow) bspgemm_comm{ctx, nullptr, rank, nranks, nullptr, nullptr};
+    if (!c) return FAIL(BSPGEMM_ERR_ALLOC, "comm");
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, rank));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_nnz), (size_t)nranks * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_bounds), ((size_t)nranks + 1) * sizeof(int)));
+    *out = c;
+    return BSPGEMM_OK;
+}
+
+extern "C" void bspgemm_comm_destroy(bspgemm_comm *c)
+{
+    if (!c) return;
+    hipSetDevice(c->ctx->device);
+    if (c->comm) ncclCommDestroy(c->comm);
+    hipFree(c->d_nnz);
+    hipFree(c->d_bounds);
+    delete c;
+}
+
+// global[i] += sum of shard nnz before the shard that owns row i; global[total_rows] = grand total
+__global__ void k_stitch_rebase(long long *global, const int *bounds, const long long *shard_nnz, int nranks)
+{
+    const int total_rows = bounds[nranks];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > total_rows) return;
+    long long base = 0;
+    int r = 0;
+    while (r < nranks && i >= bounds[r + 1]) { base += shard_nnz[r]; r++; }
+    if (i == total_rows) global[i] = base;
+    else global[i] += base;
+}
+
+extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bspgemm_result *local,
+                                                      const int *bounds, int64_t *d_row_ptr_global,
+                                                      int64_t *shard_nnz)
+{
+    if (!c || !local || !bounds || !d_row_ptr_global) return FAIL(BSPGEMM_ERR_INVALID, "stitch_row_ptr");
+    bspgemm_context *ctx = c->ctx;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int my_rows = bounds[c->rank + 1] - bounds[c->rank];
+    if (my_rows != local->rows) return FAIL(BSPGEMM_ERR_INVALID, "local result does not match bounds[rank]");
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemcpyAsync(c->d_bounds, bounds, ((size_t)c->nranks + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    // shard sizes: every rank contributes row_ptr[rows] (its nnz), 8 bytes
+    NCCLCHK(ncclAllGather(local->d_row_ptr + local->rows, c->d_nnz, 1, ncclInt64, c->comm, s));
+    // row_ptr shards have different lengths (equal-work cuts), so one broadcast per shard, grouped
+    NCCLCHK(ncclGroupStart());
+    for (int r = 0; r < c->nranks; r++) {
+        const int n = bounds[r + 1] - bounds[r];
+        if (n <= 0) continue;
+        long long *dst = reinterpret_cast<long long *>(d_row_ptr_global) + bounds[r];
+        const void *src = (r == c->rank) ? static_cast<const void *>(local->d_row_ptr) : static_cast<const void *>(dst);
+        NCCLCHK(ncclBroadcast(src, dst, (size_t)n, ncclInt64, r, c->comm, s));
+    }
+    NCCLCHK(ncclGroupEnd());
+    const int total_rows = bounds[c->nranks];
+    hipLaunchKernelGGL(k_stitch_rebase, dim3((total_rows + 1 + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<long long *>(d_row_ptr_global), c->d_bounds, c->d_nnz, c->nranks);
+    if (shard_nnz)
+        HIPCHK(hipMemcpyAsync(shard_nnz, c->d_nnz, (size_t)c->nranks * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return BSPGEMM_OK;
+}

@@ -1,0 +1,222 @@
+/*
+ * bspgemm.h -- C ABI of libbspgemm.so: boolean (pattern-only) SpGEMM  C = A*B  on MI355X.
+ *
+ * This is the drop-in boundary for the reference's row-wise Gustavson path
+ * (pavlidic/Binary-SpGEMM, final/SpGEMM_mpi_omp.c).  The reference has no plugin or FFI
+ * registry: its boundary is a handful of plain C functions on raw `int*` CSR arrays plus the
+ * command line.  Every entry point below names the reference interface it
+ * replaces (file:line, relative to the reference checkout).  Plain pointers and sizes only; no
+ * C++/torch types.  All functions are callable from C (the host side of this project is C).
+ *
+ * Conventions shared with the reference:
+ *   - CSR, 0-based; `row_ptr[rows+1]` ascending; `col_idx[nnz]`; pattern only (no values).
+ *   - argument order "col before row" in the drop-in signatures (final/SpGEMM_mpi_omp.c:15-18).
+ *   - inputs need not have sorted or duplicate-free rows; outputs always have strictly
+ *     ascending col_idx per row (the reference sorts every row, :47).
+ * Differences: the native API returns C.row_ptr as int64 (the reference's
+ * `int` overflows above 2^31-1 output nonzeros); the int32 drop-ins REFUSE (status
+ * BSPGEMM_ERR_OVERFLOW, nothing written) instead of wrapping.
+ */
+#ifndef BSPGEMM_H
+#define BSPGEMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status ------------- */
+typedef enum bspgemm_status {
+    BSPGEMM_OK            = 0,
+    BSPGEMM_ERR_INVALID   = 1,   /* bad argument (null pointer, negative size, row range)        */
+    BSPGEMM_ERR_ALLOC     = 2,   /* host or device allocation failed                            */
+    BSPGEMM_ERR_HIP       = 3,   /* a HIP runtime call failed (see bspgemm_last_error)          */
+    BSPGEMM_ERR_NO_DEVICE = 4,   /* no usable gfx950 device: the product has NO CPU fallback    */
+    BSPGEMM_ERR_OVERFLOW  = 5,   /* result does not fit the int32 drop-in interface             */
+    BSPGEMM_ERR_IO        = 6,   /* file open / parse failure                                   */
+    BSPGEMM_ERR_FORMAT    = 7,   /* Matrix Market banner / size line rejected                   */
+    BSPGEMM_ERR_COMM      = 8    /* RCCL failure in the multi-GPU exchange                      */
+} bspgemm_status;
+
+const char *bspgemm_status_string(bspgemm_status s);
+/* text of the last failure on this thread (HIP error string, file:line) */
+const char *bspgemm_last_error(void);
+
+/* ---------------------------------------------------------------- native handle API ---
+ * Replaces, with device-resident operands and int64 row_ptr, the call
+ *     SpGEMM_mpi(Acol,Arow,An, Acol,Arow,An, &nCcol,nCrow,tBlock)   final/SpGEMM_mpi_omp.c:322
+ * and the functions under it: SpGEMM_omp :71-143, SpGEMM_bigslice :15-58 (+ quickSort,
+ * final/utils.c:159-173, which has no GPU counterpart: rows are emitted in order).
+ * Upload once, multiply `times` times, download if wanted -- the reference's timed region
+ * (:320-324) likewise excludes I/O and CSR construction.                                     */
+typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
+typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
+typedef struct bspgemm_result  bspgemm_result;    /* device-resident CSR product, int64 row_ptr */
+
+bspgemm_status bspgemm_create(int device, bspgemm_context **ctx);
+void           bspgemm_destroy(bspgemm_context *ctx);
+/* run on an existing HIP stream (hipStream_t passed as void*; NULL = the context's own) */
+bspgemm_status bspgemm_set_stream(bspgemm_context *ctx, void *hip_stream);
+bspgemm_status bspgemm_synchronize(bspgemm_context *ctx);
+
+/* Copy a host CSR to the device.  `row_ptr` may be an interior pointer into a larger matrix
+ * (values absolute into `col_idx`, like &Arow[rank*tasksize] at final/SpGEMM_mpi_omp.c:171);
+ * only col_idx[row_ptr[0] .. row_ptr[rows]) is transferred and the pointers are rebased.     */
+bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, int cols,
+                                     const int *row_ptr, const int *col_idx,
+                                     bspgemm_matrix **out);
+/* Adopt device arrays the caller owns (not freed by bspgemm_matrix_free), row_ptr[0] == 0.   */
+bspgemm_status bspgemm_matrix_wrap_device(bspgemm_context *ctx, int rows, int cols, int64_t nnz,
+                                          const int *d_row_ptr, const int *d_col_idx,
+                                          bspgemm_matrix **out);
+void    bspgemm_matrix_free(bspgemm_matrix *m);
+int     bspgemm_matrix_rows(const bspgemm_matrix *m);
+int     bspgemm_matrix_cols(const bspgemm_matrix *m);
+int64_t bspgemm_matrix_nnz(const bspgemm_matrix *m);
+
+/* Rows [row_begin,row_end) of C = A*B, the job of SpGEMM_bigslice(..., start_row, end_row)
+ * (final/SpGEMM_mpi_omp.c:15-58): result row_ptr is slice-local (row_ptr[0] = 0, :26).
+ * B.rows must be >= A.cols.  Asynchronous up to the internal size read-backs; the result is
+ * complete on the context's stream when the call returns.                                    */
+bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
+                                const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                int row_begin, int row_end, bspgemm_result **C);
+
+/* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):
+ * a column k is admitted to row i only if (i,k) is in F's pattern.                           */
+bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx,
+                                       const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                       const bspgemm_matrix *F,
+                                       int row_begin, int row_end, bspgemm_result **C);
+
+int            bspgemm_result_rows(const bspgemm_result *C);
+int64_t        bspgemm_result_nnz(const bspgemm_result *C);
+const int64_t *bspgemm_result_row_ptr_device(const bspgemm_result *C);   /* rows+1 entries  */
+const int     *bspgemm_result_col_idx_device(const bspgemm_result *C);   /* nnz entries     */
+/* copy to host; either pointer may be NULL to skip that array                                */
+bspgemm_status bspgemm_result_download(bspgemm_context *ctx, const bspgemm_result *C,
+                                       int64_t *row_ptr, int *col_idx);
+void           bspgemm_result_free(bspgemm_result *C);
+
+/* Per-row work F_i = sum_{j in A_i} |B_j| ("products", the flag probes of :36-38) as an
+ * exclusive prefix over rows [0,A.rows]: prefix[rows] = F.  Used to cut GPU shards at equal
+ * work instead of equal row counts (the reference cuts An/numtasks rows, :165). */
+bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx,
+                                       const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                       int64_t *prefix_host /* A.rows+1 */);
+/* bounds[0..parts] with bounds[0]=0, bounds[parts]=A.rows, equal-F contiguous shards         */
+bspgemm_status bspgemm_partition_rows(bspgemm_context *ctx,
+                                      const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                      int parts, int *bounds);
+
+/* counters of the last bspgemm_multiply* on this context */
+typedef struct bspgemm_stats {
+    int64_t rows;            /* rows multiplied                                              */
+    int64_t nnz_a;           /* A nonzeros in those rows                                     */
+    int64_t products;        /* F                                                            */
+    int64_t nnz_c;           /* output nonzeros                                              */
+    int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
+    int64_t rows_per_bin[8]; /* [0] empty, [1..6] one-wave rows by capacity, [7] dense-window */
+    float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
+    float   ms_symbolic;     /* row work + scan + binning                                    */
+    float   ms_numeric;      /* accumulate + emit kernels (the dominant kernels)             */
+    float   ms_stitch;       /* count scan + compaction into the final col_idx               */
+    float   ms_bin[8];       /* per capacity class: duration of that class's numeric launch  */
+} bspgemm_stats;
+bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
+
+/* ---------------------------------------------------------------- int32 drop-ins ------
+ * Same argument lists and ownership as the reference functions they replace: inputs are host
+ * arrays and are not modified; `Crow` is caller memory with An+1 ints; `*Ccol` is allocated
+ * here with libc malloc so the caller's free() (final/SpGEMM_mpi_omp.c:327) stays valid.
+ * The reference functions return void and check nothing; these return a status as well and,
+ * on failure, leave *Ccol = NULL and print one line to stderr -- they never fall back to a CPU
+ * path.  `tBlock` is accepted and ignored (the GPU grid replaces OpenMP slices).             */
+
+/* replaces SpGEMM_omp, final/SpGEMM_mpi_omp.c:71-74 (all An rows; no divisibility rule) */
+int SpGEMM_hip(int *Acol, int *Arow, int An,
+               int *Bcol, int *Brow, int Bm,
+               int **Ccol, int *Crow, int tBlock);
+
+/* replaces SpGEMM_bigslice, final/SpGEMM_mpi_omp.c:15-18: rows [start_row,end_row), slice-local
+ * Crow, *Ccol pre-allocated by the caller with *Csize ints and grown with realloc if needed   */
+int SpGEMM_hip_bigslice(int *Acol, int *Arow, int An,
+                        int *Bcol, int *Brow, int Bm,
+                        int **Ccol, int *Crow, int *Csize,
+                        int start_row, int end_row);
+
+/* replaces SpGEMM_mat, Matlab/inc/BSpGEMM.h:2-4 (coder.ceval target, Matlab/SpGEMM.m:9-11):
+ * Ccol pre-allocated by the caller with the true nnz                                          */
+int SpGEMM_hip_mat(int *Acol, int *Arow, int An,
+                   int *Bcol, int *Brow, int Bm,
+                   int *Ccol, int *Crow);
+
+/* replaces SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-235 */
+int SpGEMM_hip_masked(int *Acol, int *Arow, int An,
+                      int *Bcol, int *Brow, int Bm,
+                      int *Fcol, int *Frow,
+                      int **Ccol, int *Crow, int *Csize);
+
+/* device used by the drop-ins (default 0, or env BSPGEMM_DEVICE) */
+int bspgemm_dropin_set_device(int device);
+
+/* ---------------------------------------------------------------- multi-GPU -----------
+ * Replaces SpGEMM_mpi, final/SpGEMM_mpi_omp.c:155-225: one process (or thread) per GPU, B
+ * replicated, contiguous A-row shards.  The reference gathers nnz, Ccol and Crow on rank 0
+ * with MPI_Reduce/Gather/Gatherv (:178-204) and rebases Crow serially (:211-223); here every
+ * GPU all-gathers the shard sizes and its local row_ptr over RCCL and rebases on device, so
+ * every rank ends with the global C.row_ptr; col_idx stays sharded on the GPUs.
+ * The communicator is built from an RCCL unique id that the launcher distributes (MPI,
+ * torch.distributed, a file ...): bspgemm_comm_unique_id on rank 0, then bspgemm_comm_create
+ * on every rank with the same 128 bytes.                                                      */
+typedef struct bspgemm_comm bspgemm_comm;
+#define BSPGEMM_UNIQUE_ID_BYTES 128
+bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES]);
+bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[BSPGEMM_UNIQUE_ID_BYTES],
+                                   int rank, int nranks, bspgemm_comm **comm);
+void           bspgemm_comm_destroy(bspgemm_comm *comm);
+/* All-gather and rebase: `bounds[nranks+1]` are the shard row bounds every rank used; `local`
+ * is this rank's product of rows [bounds[rank],bounds[rank+1]).  On return d_row_ptr_global
+ * (device, bounds[nranks]+1 int64) holds the stitched global row_ptr on every rank and
+ * shard_nnz[nranks] (host) the per-shard nnz.                                                 */
+bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *comm, const bspgemm_result *local,
+                                           const int *bounds, int64_t *d_row_ptr_global,
+                                           int64_t *shard_nnz);
+
+/* ---------------------------------------------------------------- host utilities (C) --
+ * Plain C, no GPU needed.                                                                    */
+
+/* replaces readCOO, final/utils.c:47-81 (with mm_read_banner final/mmio.c:96-179,
+ * mm_read_mtx_crd_size :189-217 and coo2csc final/coo2csc.c:22-64): Matrix Market pattern
+ * file -> CSR of the TRANSPOSED file matrix (the reference's argument swap at utils.c:77),
+ * entries kept in file order inside each row, duplicates kept, square assumed (n = M).
+ * The reference exit(1)s on failure (silently for fopen, with "Could not process Matrix
+ * Market banner." for the banner); this returns BSPGEMM_ERR_IO / _FORMAT so that the CLI can
+ * reproduce that behaviour.  Arrays are malloc'd; release with free().                        */
+bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
+                               uint32_t *M, uint32_t *N, uint32_t *nnz);
+/* writes a CSR as `%%MatrixMarket matrix coordinate pattern general` such that
+ * bspgemm_readCOO (and the reference's readCOO) reconstruct exactly this CSR                  */
+bspgemm_status bspgemm_write_mtx(const char *path, int rows, int cols,
+                                 const int *row_ptr, const int *col_idx);
+/* C -> Matrix Market in the FILE's orientation (transposed back), int64 row_ptr              */
+bspgemm_status bspgemm_write_result_mtx(const char *path, int rows, int cols,
+                                        const int64_t *row_ptr, const int *col_idx);
+
+/* replaces SpGEMM_valid, final/SpGEMM_mpi_omp_validity.c:290-302: exact CSR equality, 1 = same */
+int bspgemm_csr_equal(const int *Acol, const int *Arow, const int *Bcol, const int *Brow, int n);
+int bspgemm_csr_equal64(const int *Acol, const int64_t *Arow, const int *Bcol, const int64_t *Brow, int n);
+
+/* Seeded synthetic boolean matrices (the reference's inputs came from Matlab
+ * sprand via Matlab/write_spm.m:5-8).  Rows sorted, duplicates collapsed.  malloc'd outputs.  */
+bspgemm_status bspgemm_gen_uniform(int n, int d, uint64_t seed, int **row_ptr, int **col_idx);
+bspgemm_status bspgemm_gen_rmat(int scale, int edge_factor, double a, double b, double c,
+                                uint64_t seed, int **row_ptr, int **col_idx);
+bspgemm_status bspgemm_gen_powerlaw(int n, int mean_degree, double alpha, int max_degree,
+                                    uint64_t seed, int **row_ptr, int **col_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSPGEMM_H */

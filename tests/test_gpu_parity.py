@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path, called through the C ABI (libbspgemm.so), must be BIT-EXACT
+(identical row_ptr, identical sorted col_idx) against
+  (1) the committed golden vectors produced by the reference itself (tests/golden/),
+  (2) the CPU oracle (oracle/bspgemm_oracle.c, pinned to the reference) on seeded inputs that
+      exercise every accumulator path: capacity classes 64..2048, LEVELS 1..4 of the rank bitmap,
+      the dense-window kernel (one and several windows), empty / full / duplicate rows,
+      rectangular A != B, interior row ranges,
+  (3) size-independent properties at BASELINE sizes (sortedness, row_ptr monotone, shard
+      concatenation == whole product, idempotence of the boolean square on a closure).
+Integer work: the bar is exact equality; there is no tolerance anywhere in this file.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import bspgemm
+import gen
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = bspgemm.Context(0)
+    yield c
+    c.close()
+
+
+def hip_product(ctx, a_rp, a_ci, a_cols, b_rp, b_ci, b_cols, r0=0, r1=None):
+    A = ctx.upload(a_rp, a_ci, a_cols)
+    B = A if (b_rp is a_rp and b_ci is a_ci) else ctx.upload(b_rp, b_ci, b_cols)
+    C = ctx.multiply(A, B, r0, A.rows if r1 is None else r1)
+    rp, ci = C.download()
+    st = ctx.stats()
+    C.free()
+    return rp, ci, st
+
+
+def assert_same(rp, ci, erp, eci):
+    assert rp.shape == np.asarray(erp).shape
+    assert np.array_equal(rp, erp), "row_ptr differs (first at %s)" % np.flatnonzero(rp != erp)[:5]
+    assert np.array_equal(ci, eci), "col_idx differs (first at %s)" % np.flatnonzero(ci != eci)[:5]
+
+
+# ---------------------------------------------------------------- (1) golden vectors ------
+def test_validity_fixture(ctx):
+    """BASELINE config 1: Matlab/validity_test.mtx A*A, nnz 12502 -- loader + product."""
+    rp, ci, m, n = bspgemm.readCOO(os.path.join(GOLDEN, "validity_test.mtx"))
+    g = np.load(os.path.join(GOLDEN, "validity.npz"), allow_pickle=False)
+    crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
+    assert crp[-1] == 12502 and st["nnz_c"] == 12502 and st["products"] == 12502
+    assert_same(crp, cci, g["c_rp"], g["c_ci"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*_bigslice.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_bigslice_goldens(ctx, path):
+    g = np.load(path, allow_pickle=False)
+    n = int(g["n"])
+    a_rp, a_ci = g["a_rp"], g["a_ci"]
+    crp, cci, _ = hip_product(ctx, a_rp, a_ci, n, a_rp, a_ci, n)
+    assert_same(crp, cci, g["c_rp"], g["c_ci"])
+
+
+def test_omp_interior_rows_golden(ctx):
+    g = np.load(os.path.join(GOLDEN, "uniform_n4096_rows1024_3072_omp.npz"), allow_pickle=False)
+    n, r0, rows = int(g["n"]), int(g["row0"]), int(g["rows"])
+    crp, cci, _ = hip_product(ctx, g["a_rp"], g["a_ci"], n, g["a_rp"], g["a_ci"], n, r0, r0 + rows)
+    assert_same(crp, cci, g["c_rp"], g["c_ci"])
+    # the int32 drop-in with an interior Arow pointer, exactly how SpGEMM_mpi calls SpGEMM_omp (:171)
+    crow, ccol = bspgemm.SpGEMM_hip(g["a_ci"], g["a_rp"], rows, g["a_ci"], g["a_rp"], n, tBlock=64, row0=r0)
+    assert_same(crow, ccol, g["c_rp"], g["c_ci"])
+    crow, ccol = bspgemm.SpGEMM_hip_bigslice(g["a_ci"], g["a_rp"], n, g["a_ci"], g["a_rp"], n, r0, r0 + rows)
+    assert_same(crow, ccol, g["c_rp"], g["c_ci"])
+
+
+def test_rect_golden_and_mat_dropin(ctx):
+    g = np.load(os.path.join(GOLDEN, "rect_300x200x250_mat.npz"), allow_pickle=False)
+    crp, cci, _ = hip_product(ctx, g["a_rp"], g["a_ci"], 200, g["b_rp"], g["b_ci"], 250)
+    assert_same(crp, cci, g["c_rp"], g["c_ci"])
+    crow, ccol = bspgemm.SpGEMM_hip_mat(g["a_ci"], g["a_rp"], 300, g["b_ci"], g["b_rp"], 250, g["c_rp"][-1])
+    assert_same(crow, ccol, g["c_rp"], g["c_ci"])
+
+
+# ---------------------------------------------------------------- (2) oracle, every path ---
+CASES = {
+    # name: (maker, expected properties)
+    "levels1_n3000": lambda: gen.uniform(3000, 12, 201),                       # cols <= 4096
+    "levels2_uniform_n2e16_d16": lambda: gen.uniform(1 << 16, 16, 202),        # cfg-2 shape, smaller
+    "levels2_rmat_s15_mild": lambda: gen.rmat(15, 16, (0.30, 0.25, 0.25, 0.20), 203),
+    "levels2_rmat_s14_g500": lambda: gen.rmat(14, 16, (0.57, 0.19, 0.19, 0.05), 204),   # hub rows -> dense kernel
+    "levels3_uniform_n300k": lambda: gen.uniform(300000, 6, 205),              # cols > 2^18
+    "levels3_rmat_s19_sparse": lambda: gen.rmat(19, 4, (0.45, 0.22, 0.22, 0.11), 206),
+    "powerlaw_n2e15_d32": lambda: gen.powerlaw(1 << 15, 32, 207),              # cfg-5 shape, smaller
+    "special_rows": lambda: gen.with_special_rows(5000, 7, 208),
+    "dups_unsorted": lambda: gen.dups_unsorted(4097, 20, 209),
+    "banded": lambda: gen.banded(70000, 9, 210),
+    "n_not_multiple_of_64": lambda: gen.uniform(4095 + 64 * 3 + 1, 9, 211),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_against_oracle(ctx, name):
+    rp, ci, n = CASES[name]()
+    erp, eci = O.spgemm(rp, ci, rp, ci, n)
+    crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
+    assert_same(crp, cci, erp, eci)
+    assert st["products"] == O.count_products(rp, ci, rp)
+    assert st["nnz_c"] == erp[-1] and sum(st["rows_per_bin"]) == n
+
+
+def test_every_capacity_class_is_exercised(ctx):
+    """rows with F_i just below/above each class boundary 64,128,...,2048 and beyond"""
+    n = 6000
+    rng = np.random.default_rng(301)
+    # B: row j has (j % 97) + 1 entries; A rows pick B rows so that F_i sweeps 1..4000
+    b_rows = np.repeat(np.arange(n), (np.arange(n) % 97) + 1)
+    b_cols = rng.integers(0, n, size=b_rows.size)
+    b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, n)
+    blen = np.diff(b_rp)
+    targets = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025,
+               2047, 2048, 2049, 3000, 4000] * 8
+    a_rows, a_cols = [], []
+    for i, t in enumerate(targets):
+        acc = 0
+        while acc < t:
+            j = int(rng.integers(0, n))
+            if acc + blen[j] <= t + 3:
+                a_rows.append(i)
+                a_cols.append(j)
+                acc += blen[j]
+    a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, n)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, n)
+    crp, cci, st = hip_product(ctx, a_rp, a_ci, n, b_rp, b_ci, n)
+    assert_same(crp, cci, erp, eci)
+    assert all(c > 0 for c in st["rows_per_bin"]), st["rows_per_bin"]
+
+
+def test_levels4_wide_columns(ctx):
+    """cols > 2^24 -> four-level rank bitmap (128 top words); B is 2000 x 40M"""
+    a_rp, a_ci = gen.uniform_rect(1500, 2000, 8, seed=401)
+    rng = np.random.default_rng(402)
+    ncols = 40_000_000
+    rows = np.repeat(np.arange(2000), 30)
+    cols = np.concatenate([rng.integers(0, ncols, size=rows.size // 2),
+                           rng.integers(ncols - 5000, ncols, size=rows.size - rows.size // 2)])
+    b_rp, b_ci = gen._csr_from_pairs(rows, cols, 2000)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+    crp, cci, _ = hip_product(ctx, a_rp, a_ci, 2000, b_rp, b_ci, ncols)
+    assert_same(crp, cci, erp, eci)
+
+
+def test_dense_rows_several_windows(ctx):
+    """heavy rows with cols > 2^20: the dense kernel sweeps several LDS windows"""
+    ncols = 3 * (1 << 20) + 777
+    rng = np.random.default_rng(501)
+    nb = 3000
+    rows = np.repeat(np.arange(nb), 200)
+    cols = rng.integers(0, ncols, size=rows.size)
+    b_rp, b_ci = gen._csr_from_pairs(rows, cols, nb)
+    a_rows = np.concatenate([np.zeros(2500, np.int64), np.full(40, 1), np.full(900, 2), np.arange(3, 60)])
+    a_cols = rng.integers(0, nb, size=a_rows.size)
+    a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, 64)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+    crp, cci, st = hip_product(ctx, a_rp, a_ci, nb, b_rp, b_ci, ncols)
+    assert_same(crp, cci, erp, eci)
+    assert st["rows_per_bin"][7] >= 3
+
+
+def test_empty_and_degenerate(ctx):
+    z = np.zeros(65, np.int32)
+    crp, cci, _ = hip_product(ctx, z, np.zeros(0, np.int32), 64, z, np.zeros(0, np.int32), 64)
+    assert crp.tolist() == [0] * 65 and cci.size == 0
+    one_rp, one_ci = np.array([0, 1], np.int32), np.array([0], np.int32)
+    crp, cci, _ = hip_product(ctx, one_rp, one_ci, 1, one_rp, one_ci, 1)
+    assert crp.tolist() == [0, 1] and cci.tolist() == [0]
+    rp, ci, n = gen.uniform(500, 5, 601)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A, 100, 100)          # empty row range
+    assert C.rows == 0 and C.nnz == 0
+    with pytest.raises(bspgemm.BspgemmError):
+        ctx.multiply(A, A, 10, 5)
+    with pytest.raises(bspgemm.BspgemmError):
+        ctx.multiply(A, A, 0, n + 1)
+
+
+# ---------------------------------------------------------------- (3) properties at size --
+def _check_wellformed(rp, ci, ncols):
+    assert rp[0] == 0 and rp[-1] == ci.size and np.all(np.diff(rp) >= 0)
+    if ci.size:
+        assert ci.min() >= 0 and ci.max() < ncols
+        d = np.diff(ci.astype(np.int64))
+        starts = rp[1:-1][(rp[1:-1] > 0) & (rp[1:-1] < ci.size)]
+        boundary = np.zeros(ci.size - 1, dtype=bool)
+        boundary[starts - 1] = True
+        assert np.all(d[~boundary] > 0), "col_idx must be strictly ascending inside every row"
+
+
+def test_baseline_cfg2_uniform_full_size(ctx):
+    """BASELINE config 2 at full size: n=2^18, d=16, A*A; exact vs the oracle (a few seconds)."""
+    rp, ci, n = bspgemm.gen_uniform(1 << 18, 16, seed=1)
+    crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
+    _check_wellformed(crp, cci, n)
+    erp, eci = O.spgemm_omp(rp, ci, rp, ci, n, 4096, 0)
+    assert_same(crp, cci, erp, eci)
+    assert st["products"] == O.count_products(rp, ci, rp)
+
+
+def test_shards_concatenate_to_whole(ctx):
+    """row shards cut at equal work, multiplied separately, stitched == the whole product"""
+    rp, ci, n = bspgemm.gen_rmat(17, 16, (0.30, 0.25, 0.25), seed=3)
+    A = ctx.upload(rp, ci, n)
+    whole = ctx.multiply(A, A)
+    wrp, wci = whole.download()
+    bounds = ctx.partition_rows(A, A, 4)
+    assert bounds[0] == 0 and bounds[-1] == n and np.all(np.diff(bounds) >= 0)
+    prefix = ctx.row_work_prefix(A, A)
+    from bspgemm import dist as bdist
+    assert np.array_equal(bounds, bdist.shard_bounds(prefix, 4))
+    work = np.diff(prefix[bounds])
+    assert work.max() < 1.2 * work.mean(), "equal-work cut is unbalanced: %s" % work
+    parts_rp, parts_ci, base = [np.zeros(1, np.int64)], [], 0
+    for p in range(4):
+        C = ctx.multiply(A, A, int(bounds[p]), int(bounds[p + 1]))
+        r, c = C.download()
+        parts_rp.append(r[1:] + base)
+        parts_ci.append(c)
+        base += r[-1]
+    assert_same(np.concatenate(parts_rp), np.concatenate(parts_ci), wrp, wci)
+    _check_wellformed(wrp, wci, n)
+
+
+def test_rmat_scale20_properties_and_sampled_rows(ctx):
+    """R-MAT scale 20 (cfg-3 shape, 1/4 size): well-formedness + exact check of sampled row blocks"""
+    rp, ci, n = bspgemm.gen_rmat(20, 16, (0.30, 0.25, 0.25), seed=1)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A)
+    crp, cci = C.download()
+    st = ctx.stats()
+    _check_wellformed(crp, cci, n)
+    assert st["products"] == O.count_products(rp, ci, rp)
+    for r0 in (0, 1000, n // 2, n - 4096):
+        erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0, r0 + 4096)
+        assert np.array_equal(crp[r0:r0 + 4097] - crp[r0], erp)
+        assert np.array_equal(cci[crp[r0]:crp[r0 + 4096]], eci)
+
+
+def test_boolean_closure_is_idempotent(ctx):
+    """(I + A)^k reaches a fixpoint T with T*T == T (the motivating use)"""
+    n = 600
+    rng = np.random.default_rng(701)
+    rows = np.concatenate([np.arange(n), rng.integers(0, n, 500)])
+    cols = np.concatenate([np.arange(n), rng.integers(0, n, 500)])
+    rp, ci = gen._csr_from_pairs(rows, cols, n)
+    for _ in range(12):
+        A = ctx.upload(rp, ci, n)
+        C = ctx.multiply(A, A)
+        nrp, nci = C.download()
+        same = np.array_equal(nrp, rp) and np.array_equal(nci, ci)
+        rp, ci = nrp.astype(np.int32), nci
+        if same:
+            break
+    assert same, "closure did not converge"
+    erp, eci = O.spgemm(rp, ci, rp, ci, n)
+    assert_same(rp.astype(np.int64), ci, erp, eci)

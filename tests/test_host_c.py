@@ -1,0 +1,115 @@
+"""CPU-only tests of the product's host C side (loader, writer, comparator, generators)."""
+import os
+
+import numpy as np
+import pytest
+
+import bspgemm
+import gen
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_readcoo_matches_reference_goldens():
+    g = np.load(os.path.join(GOLDEN, "validity.npz"), allow_pickle=False)
+    rp, ci, m, n = bspgemm.readCOO(os.path.join(GOLDEN, "validity_test.mtx"))
+    assert (m, n) == (50000, 50000)
+    assert np.array_equal(rp, g["a_rp"]) and np.array_equal(ci, g["a_ci"])
+    g = np.load(os.path.join(GOLDEN, "loader_case_readcoo.npz"), allow_pickle=False)
+    rp, ci, m, n = bspgemm.readCOO(os.path.join(GOLDEN, "loader_case.mtx"))
+    assert np.array_equal(rp, g["row_ptr"]) and np.array_equal(ci, g["col_idx"])
+
+
+def test_readcoo_error_behaviour(tmp_path):
+    """reference: fopen failure -> exit(1) (utils.c:54), bad banner -> message + exit(1) (:56-59)"""
+    with pytest.raises(bspgemm.BspgemmError) as e:
+        bspgemm.readCOO(str(tmp_path / "nope.mtx"))
+    assert e.value.status == 6
+    p = tmp_path / "bad.mtx"
+    p.write_text("%MatrixMarket matrix coordinate pattern general\n2 2 1\n1 1\n")
+    with pytest.raises(bspgemm.BspgemmError) as e:
+        bspgemm.readCOO(str(p))
+    assert e.value.status == 7
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n% only comments\n")
+    with pytest.raises(bspgemm.BspgemmError) as e:
+        bspgemm.readCOO(str(p))
+    assert e.value.status == 7
+
+
+def test_readcoo_transposes_and_keeps_file_order(tmp_path):
+    p = tmp_path / "t.mtx"
+    # file entries (row, col): (1,2) (3,2) (2,2) (1,1) (1,2)dup   -> CSR row = file col, stable
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n3 3 5\n1 2\n3 2\n2 2\n1 1\n1 2\n")
+    rp, ci, m, n = bspgemm.readCOO(str(p))
+    assert rp.tolist() == [0, 1, 5, 5]
+    assert ci.tolist() == [0, 0, 2, 1, 0]
+    orp, oci, _, _ = O.read_mtx(str(p))
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+
+
+def test_readcoo_skips_values_of_real_files(tmp_path):
+    p = tmp_path / "r.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 2 3.5\n2 1 -1e3\n")
+    rp, ci, m, n = bspgemm.readCOO(str(p))
+    assert rp.tolist() == [0, 1, 2] and ci.tolist() == [1, 0]
+
+
+def test_write_then_read_roundtrip(tmp_path):
+    rp, ci, n = gen.uniform(300, 5, seed=3)
+    p = str(tmp_path / "w.mtx")
+    bspgemm.write_mtx(p, rp, ci)
+    rp2, ci2, m, nn = bspgemm.readCOO(p)
+    assert (m, nn) == (n, n) and np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    # and the reference's own loader agrees, where it is available
+    R = O.reference()
+    if R is not None:
+        rp3, ci3, _, _ = R.read_mtx(p)
+        assert np.array_equal(rp, rp3) and np.array_equal(ci, ci3)
+    crow, ccol = O.spgemm(rp, ci, rp, ci, n)
+    bspgemm.write_result_mtx(p, crow, ccol)
+    rp4, ci4, _, _ = bspgemm.readCOO(p)
+    assert np.array_equal(rp4, crow) and np.array_equal(ci4, ccol)
+
+
+def test_csr_equal_is_spgemm_valid():
+    rp, ci, n = gen.uniform(100, 4, seed=5)
+    assert bspgemm.csr_equal(rp, ci, rp, ci)
+    ci2 = ci.copy()
+    ci2[-1] ^= 1
+    assert not bspgemm.csr_equal(rp, ci, rp, ci2)
+    rp2 = rp.copy()
+    rp2[50] += 1
+    assert not bspgemm.csr_equal(rp, ci, rp2, ci)
+
+
+@pytest.mark.parametrize("make", [
+    lambda s: bspgemm.gen_uniform(5000, 16, seed=s),
+    lambda s: bspgemm.gen_rmat(12, 16, (0.30, 0.25, 0.25), seed=s),
+    lambda s: bspgemm.gen_rmat(11, 8, (0.57, 0.19, 0.19), seed=s),
+    lambda s: bspgemm.gen_powerlaw(4096, 32, seed=s),
+])
+def test_generators_wellformed_and_deterministic(make):
+    rp, ci, n = make(1)
+    assert rp[0] == 0 and rp[-1] == ci.size and np.all(np.diff(rp) >= 0)
+    assert ci.min() >= 0 and ci.max() < n
+    row_of = np.repeat(np.arange(n), np.diff(rp))
+    d = np.diff(ci.astype(np.int64))
+    same_row = row_of[1:] == row_of[:-1]
+    assert np.all(d[same_row] > 0), "rows must be strictly ascending (sorted, no duplicates)"
+    rp2, ci2, _ = make(1)
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+    rp3, ci3, _ = make(2)
+    assert not (np.array_equal(rp, rp3) and np.array_equal(ci, ci3))
+
+
+def test_generator_shapes():
+    rp, ci, n = bspgemm.gen_uniform(1 << 14, 16, seed=1)
+    assert n == 1 << 14 and 15.9 * n < rp[-1] <= 16 * n
+    rp, ci, n = bspgemm.gen_rmat(14, 16, (0.30, 0.25, 0.25), seed=1)
+    assert n == 1 << 14 and 0.9 * 16 * n < rp[-1] <= 16 * n
+    rp, ci, n = bspgemm.gen_powerlaw(1 << 14, 64, seed=1)
+    deg = np.diff(rp)
+    # draws are mean 64 per row; skewed column choice collapses many duplicates at small n
+    assert deg.min() >= 1 and deg.max() <= n // 16 and 20 * n < rp[-1] <= 64 * n
+    assert deg.max() > 20 * np.median(deg), "expected a heavy tail"
