@@ -78,7 +78,7 @@ def bin_of(F):
 def cpu_baseline(rp, ci, n, budget_s=12.0):
     """Reference CPU path (oracle/_ref SpGEMM_omp, else the in-repo port) on a bounded row sample."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = min(16, len(os.sched_getaffinity(0)))     # one GPU's CPU share on the box
     R = O.reference()
     kind = "reference" if R is not None else "port"
 

@@ -14,8 +14,12 @@ Mirrors the reference's interface names where they exist:
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
+
+# host-side OpenMP (generators): stay inside one GPU's CPU share on shared boxes
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, len(os.sched_getaffinity(0)))))
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)                      # binary-spgemm_amd/
@@ -217,9 +221,12 @@ class Context:
         self._h = C.c_void_p()
         _chk(lib().bspgemm_create(device, C.byref(self._h)), "bspgemm_create")
         self.device = device
+        self._children = weakref.WeakSet()      # matrices/results must go before their context
 
     def close(self):
         if self._h:
+            for ch in list(self._children):
+                ch.free()
             lib().bspgemm_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -283,6 +290,7 @@ class Context:
 class Matrix:
     def __init__(self, ctx, handle, keep):
         self.ctx, self._h, self._keep = ctx, handle, keep
+        ctx._children.add(self)
         self.rows = lib().bspgemm_matrix_rows(handle)
         self.cols = lib().bspgemm_matrix_cols(handle)
         self.nnz = lib().bspgemm_matrix_nnz(handle)
@@ -302,6 +310,7 @@ class Matrix:
 class Result:
     def __init__(self, ctx, handle):
         self.ctx, self._h = ctx, handle
+        ctx._children.add(self)
         self.rows = lib().bspgemm_result_rows(handle)
         self.nnz = lib().bspgemm_result_nnz(handle)
 
