@@ -126,7 +126,7 @@ def lib():
     L.bspgemm_comm_create.argtypes = [VP, C.c_char_p, C.c_int, C.c_int, PVP]
     L.bspgemm_comm_destroy.argtypes = [VP]
     L.bspgemm_comm_destroy.restype = None
-    L.bspgemm_comm_stitch_row_ptr.argtypes = [VP, VP, _I32P, VP, _I64P]
+    L.bspgemm_comm_stitch_row_ptr.argtypes = [VP, VP, _I32P, PVP, VP]
     U32PP = C.POINTER(C.POINTER(C.c_uint32))
     L.bspgemm_readCOO.argtypes = [C.c_char_p, U32PP, U32PP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_uint32)]

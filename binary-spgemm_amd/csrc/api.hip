@@ -595,6 +595,8 @@ struct bspgemm_comm {
     int rank, nranks;
     long long *d_nnz;      // nranks
     int *d_bounds;         // nranks+1
+    long long *d_global;   // stitched row_ptr, grown on demand
+    size_t global_cap;
 };
 
 extern "C" bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES])
@@ -613,7 +615,7 @@ extern "C" bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsign
     if (!ctx || !id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return FAIL(BSPGEMM_ERR_INVALID, "comm_create");
     *out = nullptr;
     if (bspgemm_status st = use_device(ctx)) return st;
-    bspgemm_comm *c = new (std::nothrow) bspgemm_comm{ctx, nullptr, rank, nranks, nullptr, nullptr};
+    bspgemm_comm *c = new (std::nothrow) bspgemm_comm{ctx, nullptr, rank, nranks, nullptr, nullptr, nullptr, 0};
     if (!c) return FAIL(BSPGEMM_ERR_ALLOC, "comm");
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
@@ -631,6 +633,7 @@ extern "C" void bspgemm_comm_destroy(bspgemm_comm *c)
     if (c->comm) ncclCommDestroy(c->comm);
     hipFree(c->d_nnz);
     hipFree(c->d_bounds);
+    hipFree(c->d_global);
     delete c;
 }
 
@@ -648,12 +651,23 @@ __global__ void k_stitch_rebase(long long *global, const int *bounds, const long
 }
 
 extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bspgemm_result *local,
-                                                      const int *bounds, int64_t *d_row_ptr_global,
+                                                      const int *bounds, const int64_t **d_row_ptr_global,
                                                       int64_t *shard_nnz)
 {
     if (!c || !local || !bounds || !d_row_ptr_global) return FAIL(BSPGEMM_ERR_INVALID, "stitch_row_ptr");
     bspgemm_context *ctx = c->ctx;
     if (bspgemm_status st = use_device(ctx)) return st;
+    const size_t need = (size_t)bounds[c->nranks] + 1;
+    if (need > c->global_cap) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        hipFree(c->d_global);
+        c->d_global = nullptr;
+        c->global_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_global), need * sizeof(long long)));
+        c->global_cap = need;
+    }
+    long long *global = c->d_global;
+    *d_row_ptr_global = reinterpret_cast<const int64_t *>(global);
     const int my_rows = bounds[c->rank + 1] - bounds[c->rank];
     if (my_rows != local->rows) return FAIL(BSPGEMM_ERR_INVALID, "local result does not match bounds[rank]");
     hipStream_t s = ctx->stream;
@@ -665,14 +679,14 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
     for (int r = 0; r < c->nranks; r++) {
         const int n = bounds[r + 1] - bounds[r];
         if (n <= 0) continue;
-        long long *dst = reinterpret_cast<long long *>(d_row_ptr_global) + bounds[r];
+        long long *dst = global + bounds[r];
         const void *src = (r == c->rank) ? static_cast<const void *>(local->d_row_ptr) : static_cast<const void *>(dst);
         NCCLCHK(ncclBroadcast(src, dst, (size_t)n, ncclInt64, r, c->comm, s));
     }
     NCCLCHK(ncclGroupEnd());
     const int total_rows = bounds[c->nranks];
     hipLaunchKernelGGL(k_stitch_rebase, dim3((total_rows + 1 + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<long long *>(d_row_ptr_global), c->d_bounds, c->d_nnz, c->nranks);
+                       global, c->d_bounds, c->d_nnz, c->nranks);
     if (shard_nnz)
         HIPCHK(hipMemcpyAsync(shard_nnz, c->d_nnz, (size_t)c->nranks * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -177,11 +177,12 @@ bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[
                                    int rank, int nranks, bspgemm_comm **comm);
 void           bspgemm_comm_destroy(bspgemm_comm *comm);
 /* All-gather and rebase: `bounds[nranks+1]` are the shard row bounds every rank used; `local`
- * is this rank's product of rows [bounds[rank],bounds[rank+1]).  On return d_row_ptr_global
- * (device, bounds[nranks]+1 int64) holds the stitched global row_ptr on every rank and
- * shard_nnz[nranks] (host) the per-shard nnz.                                                 */
+ * is this rank's product of rows [bounds[rank],bounds[rank+1]).  On return *d_row_ptr_global
+ * points at a device buffer owned by `comm` (bounds[nranks]+1 int64, valid until the next
+ * stitch or bspgemm_comm_destroy) holding the stitched global row_ptr on every rank, and
+ * shard_nnz[nranks] (host, may be NULL) the per-shard nnz.                                    */
 bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *comm, const bspgemm_result *local,
-                                           const int *bounds, int64_t *d_row_ptr_global,
+                                           const int *bounds, const int64_t **d_row_ptr_global,
                                            int64_t *shard_nnz);
 
 /* ---------------------------------------------------------------- host utilities (C) --
