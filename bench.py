@@ -202,8 +202,8 @@ def main():
     bytes_dom = int(4 * F_row[sel].sum() + 4 * c_row[sel].sum() + 12 * a_row[sel].sum() + 12 * sel.sum())
     ms_dom = float(bin_ms[dom])
     achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (3 if n > (1 << 18) else (2 if n > 4096 else 1),
-                                                     BIN_CAPS[dom] // 64)) if 1 <= dom <= 6 else "k_dense_rows"
+    levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
+    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom <= 6 else "k_dense_rows"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
                 "bytes_per_launch": bytes_dom, "ms_per_launch": round(ms_dom, 4),

@@ -76,8 +76,12 @@ struct bspgemm_context {
     bool own_stream = false;
     // per-row workspace (capacity rows_cap rows)
     size_t rows_cap = 0;
-    long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr;
-    int *cnt = nullptr, *bin_rows = nullptr, *bin_count = nullptr;
+    long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr;
+    int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
+    RowRec *rec = nullptr;
+    // per-A-nonzero workspace: (start,length) of the B row behind every A nonzero
+    size_t ab_cap = 0;
+    int2 *ab = nullptr;
     // upper-bound placed rows
     size_t tmp_cap = 0;
     int *tmp = nullptr;
@@ -152,7 +156,8 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
-    hipFree(ctx->cnt); hipFree(ctx->bin_rows); hipFree(ctx->bin_count); hipFree(ctx->tmp);
+    hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab);
     if (ctx->h) hipHostFree(ctx->h);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->ev_bin) if (e) hipEventDestroy(e);
@@ -241,9 +246,11 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
 {
     if (rows <= ctx->rows_cap) return BSPGEMM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_rows);
-    ctx->F = ctx->Fprefix = ctx->partials = nullptr;
-    ctx->cnt = ctx->bin_rows = nullptr;
+    hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_tiles);
+    hipFree(ctx->rec); hipFree(ctx->recpre);
+    ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = nullptr;
+    ctx->cnt = ctx->bin_tiles = nullptr;
+    ctx->rec = nullptr;
     ctx->rows_cap = 0;
     const size_t cap = rows + rows / 8 + 64;
     const size_t tiles = cap / 2048 + 2;
@@ -251,8 +258,23 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fprefix), (cap + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->partials), (tiles + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->cnt), cap * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_rows), (size_t)kNumBins * cap * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
     ctx->rows_cap = cap;
+    return BSPGEMM_OK;
+}
+
+static bspgemm_status ensure_ab(bspgemm_context *ctx, size_t pairs)
+{
+    if (pairs <= ctx->ab_cap) return BSPGEMM_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->ab);
+    ctx->ab = nullptr;
+    ctx->ab_cap = 0;
+    const size_t cap = pairs + pairs / 16 + 64;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->ab), cap * sizeof(int2)));
+    ctx->ab_cap = cap;
     return BSPGEMM_OK;
 }
 
@@ -291,6 +313,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     const int R = row_end - row_begin;
     hipStream_t s = ctx->stream;
     if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+    if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
 
     bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr};
     if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
@@ -309,9 +332,9 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_row_ptr), ((size_t)R + 1) * sizeof(long long), s));
 
     // ---- symbolic: per-row products, their prefix, capacity bins -----------------------
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, s);
-    launch_scan_and_bin(ctx->F, R, row_begin, ctx->Fprefix, ctx->partials, ctx->bin_rows, ctx->bin_count,
-                        ctx->cnt, s);
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
+    launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, s);
     HostScalars *h = ctx->h;
     HIPCHK_C(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -325,16 +348,16 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
 
     // ---- numeric: accumulate + emit every row at its upper-bound offset -----------------
     const int levels = levels_for_cols(B->cols);
+    size_t bin_start[kNumBins + 1] = {0, 0};               // class b's segment of rec[] (class 0 has none)
+    for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
     for (int b = 1; b <= kWaveBins; b++) {
         HIPCHK_C(hipEventRecord(ctx->ev_bin[b], s));
-        launch_wave_rows(b, levels, A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols,
-                         ctx->bin_rows + (size_t)b * R, h->bin_count[b], row_begin, ctx->Fprefix,
-                         ctx->tmp, ctx->cnt, s);
+        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, ctx->rec + bin_start[b],
+                         ctx->recpre + bin_start[b], h->bin_count[b], row_begin, ctx->tmp, ctx->cnt, s);
     }
     HIPCHK_C(hipEventRecord(ctx->ev_bin[7], s));
-    HIPCHK_C(launch_dense_rows(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols,
-                               ctx->bin_rows + (size_t)7 * R, h->bin_count[7], row_begin, ctx->Fprefix,
-                               ctx->tmp, ctx->cnt, s));
+    HIPCHK_C(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, ctx->rec + bin_start[7],
+                               ctx->recpre + bin_start[7], h->bin_count[7], row_begin, ctx->tmp, ctx->cnt, s));
     HIPCHK_C(hipGetLastError());
     HIPCHK_C(hipEventRecord(ctx->ev_bin[8], s));
     HIPCHK_C(hipEventRecord(ctx->ev[2], s));
@@ -346,7 +369,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     C->nnz = h->nnzC;
     HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int), s));
     launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->d_col_idx, s);
-    launch_compact_big(ctx->tmp, ctx->Fprefix, C->d_row_ptr, ctx->bin_rows + (size_t)7 * R, h->bin_count[7],
+    launch_compact_big(ctx->tmp, ctx->Fprefix, C->d_row_ptr, ctx->rec + bin_start[7], h->bin_count[7],
                        row_begin, C->d_col_idx, s);
     HIPCHK_C(hipGetLastError());
     HIPCHK_C(hipEventRecord(ctx->ev[3], s));
@@ -426,9 +449,10 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = use_device(ctx)) return st;
     const int R = A->rows;
     if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, 0, R, ctx->F, ctx->stream);
-    launch_scan_and_bin(ctx->F, R, 0, ctx->Fprefix, ctx->partials, ctx->bin_rows, ctx->bin_count, ctx->cnt,
-                        ctx->stream);
+    if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, 0, R, ctx->F, ctx->ab, ctx->stream);
+    launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
+                        ctx->rec, ctx->recpre, ctx->cnt, ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BSPGEMM_OK;

@@ -16,14 +16,12 @@ namespace bsp {
 constexpr int kDenseThreads = 1024;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
 
-__global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int *__restrict__ Arow,
-                                                              const int *__restrict__ Acol,
-                                                              const int *__restrict__ Brow,
+__global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
-                                                              const int *__restrict__ rows,
+                                                              const RowRec *__restrict__ rec,
+                                                              const long long *__restrict__ recpre,
                                                               int row_begin,
-                                                              const long long *__restrict__ Fprefix,
                                                               int *__restrict__ tmp,
                                                               int *__restrict__ cnt)
 {
@@ -36,9 +34,10 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int *__restr
     for (int t = tid; t < wwords; t += kDenseThreads) bm[t] = 0ull;
     __syncthreads();
 
-    const int i = rows[blockIdx.x];
-    const int a0 = Arow[i], a1 = Arow[i + 1];
-    int *out = tmp + Fprefix[i - row_begin];
+    const RowRec q = rec[blockIdx.x];
+    const int i = q.row;
+    const int a0 = q.a0, a1 = q.a0 + q.alen;
+    int *out = tmp + recpre[blockIdx.x];
     const long long W = (long long)wwords * 64;
     const int nwin = (int)(((long long)cols + W - 1) / W);
     const int group = tid >> 4, sub = tid & 15;                 // 64 groups of 16 lanes
@@ -48,8 +47,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int *__restr
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         for (int jj = a0 + group; jj < a1; jj += kDenseThreads / 16) {
-            const int j = Acol[jj];
-            const int bs = Brow[j], be = Brow[j + 1];
+            const int2 e = ab[jj];
+            const int bs = e.x, be = e.x + e.y;
             for (int k = bs + sub; k < be; k += 16) {
                 const long long c = (long long)Bcol[k] - lo;
                 if (c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
@@ -86,9 +85,9 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int *__restr
     if (tid == 0) cnt[i - row_begin] = total;
 }
 
-hipError_t launch_dense_rows(const int *Arow, const int *Acol, const int *Brow, const int *Bcol,
-                             int cols, const int *rows, int nrows, int row_begin,
-                             const long long *Fprefix, int *tmp, int *cnt, hipStream_t s)
+hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
+                             const RowRec *rec, const long long *recpre, int nrows, int row_begin,
+                             int *tmp, int *cnt, hipStream_t s)
 {
     if (nrows <= 0) return hipSuccess;
     long long words = ((long long)cols + 63) / 64;
@@ -102,8 +101,8 @@ hipError_t launch_dense_rows(const int *Arow, const int *Acol, const int *Brow, 
         if (e != hipSuccess) return e;
         attr_set_for = 128 * 1024;
     }
-    hipLaunchKernelGGL(k_dense_rows, dim3(nrows), dim3(kDenseThreads), bytes, s, Arow, Acol, Brow, Bcol,
-                       cols, (int)words, rows, row_begin, Fprefix, tmp, cnt);
+    hipLaunchKernelGGL(k_dense_rows, dim3(nrows), dim3(kDenseThreads), bytes, s, ab, Bcol,
+                       cols, (int)words, rec, recpre, row_begin, tmp, cnt);
     return hipGetLastError();
 }
 
@@ -113,6 +112,7 @@ hipError_t launch_dense_rows(const int *Arow, const int *Acol, const int *Brow, 
 // (4 B read + 4 B written per output nonzero), one wave per 8 consecutive rows; rows longer
 // than 8192 entries are left to a workgroup-per-row kernel.
 constexpr int kCompactBigRow = 8192;
+constexpr int kCompactRows = 8;          // consecutive rows copied by one wave
 
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
@@ -121,13 +121,13 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
 {
     const int lane = threadIdx.x & 63;
     const long long wave_global = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long r0 = wave_global * kRowsPerWave;
+    const long long r0 = wave_global * kCompactRows;
     if (r0 >= nrows) return;
     // lanes 0..8 fetch the row_ptr window, lanes 0..7 the source offsets
     long long rp = 0, fp = 0;
-    if (lane <= kRowsPerWave && r0 + lane <= nrows) rp = row_ptr[r0 + lane];
-    if (lane < kRowsPerWave && r0 + lane < nrows) fp = Fprefix[r0 + lane];
-    for (int k = 0; k < kRowsPerWave; k++) {
+    if (lane <= kCompactRows && r0 + lane <= nrows) rp = row_ptr[r0 + lane];
+    if (lane < kCompactRows && r0 + lane < nrows) fp = Fprefix[r0 + lane];
+    for (int k = 0; k < kCompactRows; k++) {
         if (r0 + k >= nrows) break;
         const long long d0 = __shfl(rp, k, 64), d1 = __shfl(rp, k + 1, 64);
         const long long s0 = __shfl(fp, k, 64);
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
 __global__ __launch_bounds__(1024) void k_compact_big(const int *__restrict__ tmp,
                                                       const long long *__restrict__ Fprefix,
                                                       const long long *__restrict__ row_ptr,
-                                                      const int *__restrict__ rows, int row_begin,
+                                                      const RowRec *__restrict__ rec, int row_begin,
                                                       int *__restrict__ col_idx)
 {
-    const int r = rows[blockIdx.x] - row_begin;
+    const int r = rec[blockIdx.x].row - row_begin;
     const long long d0 = row_ptr[r], len = row_ptr[r + 1] - d0, s0 = Fprefix[r];
     if (len <= kCompactBigRow) return;
     for (long long t = threadIdx.x; t < len; t += 1024) col_idx[d0 + t] = tmp[s0 + t];
@@ -153,16 +153,16 @@ void launch_compact(const int *tmp, const long long *Fprefix, const long long *r
                     int *col_idx, hipStream_t s)
 {
     if (nrows <= 0) return;
-    const long long rows_per_wg = 4ll * kRowsPerWave;
+    const long long rows_per_wg = 4ll * kCompactRows;
     const int grid = (int)((nrows + rows_per_wg - 1) / rows_per_wg);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, nrows, col_idx);
 }
 
 void launch_compact_big(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                        const int *rows, int nrows, int row_begin, int *col_idx, hipStream_t s)
+                        const RowRec *rec, int nrows, int row_begin, int *col_idx, hipStream_t s)
 {
     if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_compact_big, dim3(nrows), dim3(1024), 0, s, tmp, Fprefix, row_ptr, rows, row_begin,
+    hipLaunchKernelGGL(k_compact_big, dim3(nrows), dim3(1024), 0, s, tmp, Fprefix, row_ptr, rec, row_begin,
                        col_idx);
 }
 

@@ -89,7 +89,7 @@ def test_rect_golden_and_mat_dropin(ctx):
 # ---------------------------------------------------------------- (2) oracle, every path ---
 CASES = {
     # name: (maker, expected properties)
-    "levels1_n3000": lambda: gen.uniform(3000, 12, 201),                       # cols <= 4096
+    "levels1_n3000": lambda: gen.uniform(3000, 12, 201),                       # cols <= 8192
     "levels2_uniform_n2e16_d16": lambda: gen.uniform(1 << 16, 16, 202),        # cfg-2 shape, smaller
     "levels2_rmat_s15_mild": lambda: gen.rmat(15, 16, (0.30, 0.25, 0.25, 0.20), 203),
     "levels2_rmat_s14_g500": lambda: gen.rmat(14, 16, (0.57, 0.19, 0.19, 0.05), 204),   # hub rows -> dense kernel
@@ -140,11 +140,11 @@ def test_every_capacity_class_is_exercised(ctx):
     assert all(c > 0 for c in st["rows_per_bin"]), st["rows_per_bin"]
 
 
-def test_levels4_wide_columns(ctx):
-    """cols > 2^24 -> four-level rank bitmap (128 top words); B is 2000 x 40M"""
+@pytest.mark.parametrize("ncols", [40_000_000, 300_000_000], ids=["levels4_40M", "levels5_300M"])
+def test_wide_columns(ctx, ncols):
+    """cols > 2^23 -> four 5-bit levels, cols > 2^28 -> five; B is 2000 x ncols"""
     a_rp, a_ci = gen.uniform_rect(1500, 2000, 8, seed=401)
     rng = np.random.default_rng(402)
-    ncols = 40_000_000
     rows = np.repeat(np.arange(2000), 30)
     cols = np.concatenate([rng.integers(0, ncols, size=rows.size // 2),
                            rng.integers(ncols - 5000, ncols, size=rows.size - rows.size // 2)])
