@@ -368,9 +368,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_C(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
     HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int), s));
-    launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->d_col_idx, s);
-    launch_compact_big(ctx->tmp, ctx->Fprefix, C->d_row_ptr, ctx->rec + bin_start[7], h->bin_count[7],
-                       row_begin, C->d_col_idx, s);
+    launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->nnz, C->d_col_idx, s);
     HIPCHK_C(hipGetLastError());
     HIPCHK_C(hipEventRecord(ctx->ev[3], s));
     HIPCHK_C(hipStreamSynchronize(s));

@@ -109,61 +109,80 @@ hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
 // ---------------------------------------------------------------------------------------
 // Compaction: every row was written at its upper-bound offset Fprefix[r]; now that the counts
 // are scanned into C.row_ptr the rows are copied to their final place.  Pure streaming copy
-// (4 B read + 4 B written per output nonzero), one wave per 8 consecutive rows; rows longer
-// than 8192 entries are left to a workgroup-per-row kernel.
-constexpr int kCompactBigRow = 8192;
-constexpr int kCompactRows = 8;          // consecutive rows copied by one wave
+// (4 B read + 4 B written per output nonzero), driven by the DESTINATION: a workgroup owns
+// 16384 consecutive output nonzeros (64 KiB of C.col_idx), finds the rows that cover them by a
+// binary search in C.row_ptr, keeps their (row_ptr, shift) pairs in LDS 256 rows at a time and
+// copies 16 B per lane whenever four outputs lie in one row -- stores are always 16-B aligned
+// and fully coalesced, loads are the same stream displaced by the row's shift.  Work per
+// workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
+constexpr int kCompactChunk = 16384;     // output nonzeros per workgroup
+constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
+
+struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
 
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
                                                  const long long *__restrict__ row_ptr, int nrows,
-                                                 int *__restrict__ col_idx)
+                                                 long long nnz, int *__restrict__ col_idx)
 {
-    const int lane = threadIdx.x & 63;
-    const long long wave_global = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long long r0 = wave_global * kCompactRows;
-    if (r0 >= nrows) return;
-    // lanes 0..8 fetch the row_ptr window, lanes 0..7 the source offsets
-    long long rp = 0, fp = 0;
-    if (lane <= kCompactRows && r0 + lane <= nrows) rp = row_ptr[r0 + lane];
-    if (lane < kCompactRows && r0 + lane < nrows) fp = Fprefix[r0 + lane];
-    for (int k = 0; k < kCompactRows; k++) {
-        if (r0 + k >= nrows) break;
-        const long long d0 = __shfl(rp, k, 64), d1 = __shfl(rp, k + 1, 64);
-        const long long s0 = __shfl(fp, k, 64);
-        const long long len = d1 - d0;
-        if (len > kCompactBigRow) continue;
-        for (long long t = lane; t < len; t += 64) col_idx[d0 + t] = tmp[s0 + t];
+    __shared__ long long rp[kCompactBatch + 1];
+    __shared__ long long sh[kCompactBatch];      // source offset - destination offset of the row
+    __shared__ int r_first;
+    const int tid = threadIdx.x;
+    const long long o0 = (long long)blockIdx.x * kCompactChunk;
+    const long long o1 = (o0 + kCompactChunk < nnz) ? o0 + kCompactChunk : nnz;
+    if (tid == 0) {
+        // last row r with row_ptr[r] <= o0: it is non-empty and contains output o0
+        int lo = 0, hi = nrows;                  // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (row_ptr[mid] <= o0) lo = mid; else hi = mid;
+        }
+        r_first = lo;
+    }
+    __syncthreads();
+    int rbase = r_first;
+    while (true) {
+        const int nb = (nrows - rbase < kCompactBatch) ? nrows - rbase : kCompactBatch;   // rows staged
+        __syncthreads();
+        for (int t = tid; t <= nb; t += 256) rp[t] = row_ptr[rbase + t];
+        __syncthreads();
+        for (int t = tid; t < nb; t += 256) sh[t] = Fprefix[rbase + t] - rp[t];
+        __syncthreads();
+        const long long b0 = rp[0] > o0 ? rp[0] : o0;          // outputs covered by this batch and chunk
+        const long long b1 = rp[nb] < o1 ? rp[nb] : o1;
+        for (long long g = (b0 >> 2) + tid; (g << 2) < b1; g += 256) {
+            const long long o = g << 2;
+            const long long oo = o > b0 ? o : b0;
+            int lo = 0, hi = nb;                 // rp[lo] <= oo < rp[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (rp[mid] <= oo) lo = mid; else hi = mid;
+            }
+            if (o >= b0 && o + 3 < b1 && o + 3 < rp[lo + 1]) {
+                const Int4U v = *reinterpret_cast<const Int4U *>(tmp + o + sh[lo]);   // source only dword aligned
+                *reinterpret_cast<int4 *>(col_idx + o) = make_int4(v.x, v.y, v.z, v.w);
+            } else {
+                int r = lo;
+                for (int e = 0; e < 4; e++) {
+                    const long long oe = o + e;
+                    if (oe < b0 || oe >= b1) continue;
+                    while (rp[r + 1] <= oe) r++;
+                    col_idx[oe] = tmp[oe + sh[r]];
+                }
+            }
+        }
+        if (rp[nb] >= o1 || rbase + nb >= nrows) break;        // uniform: every thread reads the same LDS
+        rbase += nb;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_compact_big(const int *__restrict__ tmp,
-                                                      const long long *__restrict__ Fprefix,
-                                                      const long long *__restrict__ row_ptr,
-                                                      const RowRec *__restrict__ rec, int row_begin,
-                                                      int *__restrict__ col_idx)
-{
-    const int r = rec[blockIdx.x].row - row_begin;
-    const long long d0 = row_ptr[r], len = row_ptr[r + 1] - d0, s0 = Fprefix[r];
-    if (len <= kCompactBigRow) return;
-    for (long long t = threadIdx.x; t < len; t += 1024) col_idx[d0 + t] = tmp[s0 + t];
-}
-
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr, int nrows,
-                    int *col_idx, hipStream_t s)
+                    long long nnz, int *col_idx, hipStream_t s)
 {
-    if (nrows <= 0) return;
-    const long long rows_per_wg = 4ll * kCompactRows;
-    const int grid = (int)((nrows + rows_per_wg - 1) / rows_per_wg);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, nrows, col_idx);
-}
-
-void launch_compact_big(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                        const RowRec *rec, int nrows, int row_begin, int *col_idx, hipStream_t s)
-{
-    if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_compact_big, dim3(nrows), dim3(1024), 0, s, tmp, Fprefix, row_ptr, rec, row_begin,
-                       col_idx);
+    if (nrows <= 0 || nnz <= 0) return;
+    const int grid = (int)((nnz + kCompactChunk - 1) / kCompactChunk);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, nrows, nnz, col_idx);
 }
 
 }  // namespace bsp

@@ -58,13 +58,9 @@ hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 
-// tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..)
+// tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..), nnz = row_ptr[nrows]
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                    int nrows, int *col_idx, hipStream_t s);
-
-// rows longer than 8192 entries (listed in the dense class) are copied by a workgroup each
-void launch_compact_big(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                        const RowRec *rec, int nrows, int row_begin, int *col_idx, hipStream_t s);
+                    int nrows, long long nnz, int *col_idx, hipStream_t s);
 
 // row_ptr rebasing helper for interior-pointer uploads
 void launch_rebase_i32(int *row_ptr, int n, int base, hipStream_t s);
