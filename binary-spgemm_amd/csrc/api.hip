@@ -88,6 +88,10 @@ struct bspgemm_context {
     HostScalars *h = nullptr;          // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_bin[kNumBins + 1] = {};   // brackets of the per-class numeric launches
+    // freed result buffers, reused by the next multiply (results are allocated per call like the
+    // reference's per-call malloc of Ccol, final/SpGEMM_mpi_omp.c:115, without paying hipMalloc)
+    struct CachedBuf { void *p; size_t bytes; };
+    CachedBuf cache[8] = {};
     bspgemm_stats stats;
     bool stats_valid = false;
 };
@@ -139,13 +143,6 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
     for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
     for (auto &e : ctx->ev_bin) HIPCHK(hipEventCreate(&e));
-    // keep freed result buffers in the pool: results are allocated per multiply, like the
-    // reference's per-call malloc of Ccol (final/SpGEMM_mpi_omp.c:115)
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t thr = UINT64_MAX;
-        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     *out = ctx;
     return BSPGEMM_OK;
 }
@@ -161,6 +158,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     if (ctx->h) hipHostFree(ctx->h);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->ev_bin) if (e) hipEventDestroy(e);
+    for (auto &c : ctx->cache) if (c.p) hipFree(c.p);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -291,6 +289,50 @@ static bspgemm_status ensure_tmp(bspgemm_context *ctx, size_t ints)
     return BSPGEMM_OK;
 }
 
+// result buffers: best fit from the context's cache of freed results, else hipMalloc
+static hipError_t result_alloc(bspgemm_context *ctx, void **out, size_t bytes)
+{
+    int best = -1;
+    for (int i = 0; i < 8; i++) {
+        const auto &c = ctx->cache[i];
+        if (c.p && c.bytes >= bytes && c.bytes <= 2 * bytes + (1 << 20) &&
+            (best < 0 || c.bytes < ctx->cache[best].bytes))
+            best = i;
+    }
+    if (best >= 0) {
+        *out = ctx->cache[best].p;
+        ctx->cache[best].p = nullptr;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {                     // drop the cache and retry once
+        for (auto &c : ctx->cache) if (c.p) { hipFree(c.p); c.p = nullptr; }
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
+static size_t result_bytes_rowptr(int rows) { return ((size_t)rows + 1) * sizeof(long long); }
+static size_t result_bytes_colidx(long long nnz) { return ((size_t)nnz + 4) * sizeof(int); }
+
+static void result_release(bspgemm_context *ctx, void *p, size_t bytes)
+{
+    if (!p) return;
+    int slot = -1;
+    for (int i = 0; i < 8; i++)
+        if (!ctx->cache[i].p) { slot = i; break; }
+    if (slot < 0) {                                     // evict the smallest cached buffer
+        slot = 0;
+        for (int i = 1; i < 8; i++)
+            if (ctx->cache[i].bytes < ctx->cache[slot].bytes) slot = i;
+        if (ctx->cache[slot].bytes >= bytes) { hipFree(p); return; }
+        hipFree(ctx->cache[slot].p);
+    }
+    ctx->cache[slot].p = p;
+    ctx->cache[slot].bytes = bytes;
+}
+
 // ------------------------------------------------------------------ multiply -------------
 static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
                                      int row_begin, int row_end)
@@ -329,7 +371,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     } while (0)
 
     HIPCHK_C(hipEventRecord(ctx->ev[0], s));
-    HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_row_ptr), ((size_t)R + 1) * sizeof(long long), s));
+    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
 
     // ---- symbolic: per-row products, their prefix, capacity bins -----------------------
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
@@ -367,7 +409,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_C(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
-    HIPCHK_C(hipMallocAsync(reinterpret_cast<void **>(&C->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int), s));
+    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(C->nnz)));
     launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->nnz, C->d_col_idx, s);
     HIPCHK_C(hipGetLastError());
     HIPCHK_C(hipEventRecord(ctx->ev[3], s));
@@ -426,8 +468,8 @@ extern "C" void bspgemm_result_free(bspgemm_result *C)
 {
     if (!C) return;
     hipSetDevice(C->ctx->device);
-    if (C->d_row_ptr) hipFreeAsync(C->d_row_ptr, C->ctx->stream);
-    if (C->d_col_idx) hipFreeAsync(C->d_col_idx, C->ctx->stream);
+    result_release(C->ctx, C->d_row_ptr, result_bytes_rowptr(C->rows));
+    result_release(C->ctx, C->d_col_idx, result_bytes_colidx(C->nnz));
     delete C;
 }
 
