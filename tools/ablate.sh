@@ -1,0 +1,10 @@
+#!/bin/bash
+# timing-only ablation of k_wave_rows (run on the GPU box): rebuilds the LEVELS=3 unit with
+# BSP_ABLATE=1..4,0 and prints the per-class numeric times of bench.py
+cd "$(dirname "$0")/.."
+for a in 1 2 3 4 0; do
+  rm -f binary-spgemm_amd/build/wave_rows_L3.o
+  make -C binary-spgemm_amd ABLATE=$a -j16 > /dev/null 2>&1
+  python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.load(sys.stdin); print('ABLATE=$a', d['ms_per_step'], d['whole_job']['rank0_ms_per_bin'])"
+done
