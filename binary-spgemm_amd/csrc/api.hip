@@ -63,17 +63,27 @@ extern "C" const char *bspgemm_status_string(bspgemm_status s)
 }
 
 // ------------------------------------------------------------------ objects --------------
+constexpr int kMaxTiles = 16;   // row super-tiles whose compaction overlaps the next tile's accumulate
+
 struct HostScalars {
     long long totalF;
     long long nnzC;
     int bin_count[kNumBins];
     int a_lo, a_hi;
+    long long fb[kMaxTiles + 1];        // Fprefix at the super-tile boundaries
 };
 
 struct bspgemm_context {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream_b = nullptr;     // second accumulate stream (capacity classes run concurrently)
+    hipStream_t stream_c = nullptr;     // compaction stream
+    hipEvent_t ev_tile[kMaxTiles][3] = {};          // per super-tile: classes on stream_b done / scan done / start fence
+    hipEvent_t ev_cls[kMaxTiles][kNumBins][2] = {}; // per (super-tile, class): launch brackets
+    hipEvent_t ev_join = nullptr;
+    int *h_bin_tiles = nullptr;         // pinned copy of bin_tiles
+    size_t h_bin_tiles_cap = 0;
     // per-row workspace (capacity rows_cap rows)
     size_t rows_cap = 0;
     long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr;
@@ -110,6 +120,7 @@ struct bspgemm_result {
     long long nnz;
     long long *d_row_ptr;
     int *d_col_idx;
+    long long col_cap;      // entries allocated for d_col_idx (upper bound F >= nnz)
 };
 
 static bspgemm_status use_device(bspgemm_context *ctx)
@@ -143,6 +154,11 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
     for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
     for (auto &e : ctx->ev_bin) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (auto &t : ctx->ev_tile) for (auto &e : t) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &t : ctx->ev_cls) for (auto &c : t) for (auto &e : c) HIPCHK(hipEventCreate(&e));
     *out = ctx;
     return BSPGEMM_OK;
 }
@@ -159,6 +175,12 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->ev_bin) if (e) hipEventDestroy(e);
     for (auto &c : ctx->cache) if (c.p) hipFree(c.p);
+    if (ctx->stream_b) { hipStreamSynchronize(ctx->stream_b); hipStreamDestroy(ctx->stream_b); }
+    if (ctx->stream_c) { hipStreamSynchronize(ctx->stream_c); hipStreamDestroy(ctx->stream_c); }
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    for (auto &t : ctx->ev_tile) for (auto &e : t) if (e) hipEventDestroy(e);
+    for (auto &t : ctx->ev_cls) for (auto &c : t) for (auto &e : c) if (e) hipEventDestroy(e);
+    if (ctx->h_bin_tiles) hipHostFree(ctx->h_bin_tiles);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -257,6 +279,9 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->partials), (tiles + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->cnt), cap * sizeof(int)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
+    if (ctx->h_bin_tiles) hipHostFree(ctx->h_bin_tiles);
+    ctx->h_bin_tiles = nullptr;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_bin_tiles), (tiles + 1) * kNumBins * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
     ctx->rows_cap = cap;
@@ -357,7 +382,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
     if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
 
-    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr};
+    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
     if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
     auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
 #define HIPCHK_C(call)                                                                      \
@@ -370,10 +395,27 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
         }                                                                                  \
     } while (0)
 
+    hipStream_t sB = ctx->stream_b, sC = ctx->stream_c;
     HIPCHK_C(hipEventRecord(ctx->ev[0], s));
     HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
 
-    // ---- symbolic: per-row products, their prefix, capacity bins -----------------------
+    // Row super-tiles (multiples of the 2048-row scan tile).  Tile k's rows are accumulated, their
+    // counts scanned, and their compaction runs on its own stream while tile k+1 is accumulated.
+    const int scan_tiles = (R + 2047) / 2048;
+    int T = 2;
+    if (const char *e = getenv("BSPGEMM_TILES")) T = atoi(e);
+    if (T < 1) T = 1;
+    if (T > kMaxTiles) T = kMaxTiles;
+    if (R < (1 << 18)) T = 1;
+    if (T > scan_tiles && scan_tiles > 0) T = scan_tiles;
+    int tb[kMaxTiles + 1];
+    for (int k = 0; k <= T; k++) {
+        long long t = (long long)scan_tiles * k / T * 2048;
+        tb[k] = (k == T || t > R) ? R : (int)t;
+    }
+    auto tile_index = [&](int row) { return row >= R ? scan_tiles : row / 2048; };
+
+    // ---- symbolic: per-row products, their prefix, capacity classes ---------------------
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, s);
@@ -382,38 +424,67 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_C(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (R > 0) {
+        HIPCHK_C(hipMemcpyAsync(ctx->h_bin_tiles, ctx->bin_tiles, ((size_t)scan_tiles + 1) * kNumBins * sizeof(int),
+                                hipMemcpyDeviceToHost, s));
+        for (int k = 0; k <= T; k++)
+            HIPCHK_C(hipMemcpyAsync(&h->fb[k], ctx->Fprefix + tb[k], sizeof(long long), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK_C(hipEventRecord(ctx->ev[1], s));
     HIPCHK_C(hipStreamSynchronize(s));
     const long long totalF = R > 0 ? h->totalF : 0;
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
     if (bspgemm_status st = ensure_tmp(ctx, (size_t)totalF + 1)) return bail(st);
+    // C.col_idx is taken with the upper-bound size F (known now) so that no size read-back sits
+    // between the accumulate and the compaction of a tile; nnz(C) <= F entries of it are used
+    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(totalF)));
+    C->col_cap = totalF;
 
-    // ---- numeric: accumulate + emit every row at its upper-bound offset -----------------
+    // ---- numeric + stitch, pipelined over the super-tiles --------------------------------
     const int levels = levels_for_cols(B->cols);
     size_t bin_start[kNumBins + 1] = {0, 0};               // class b's segment of rec[] (class 0 has none)
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
-    for (int b = 1; b <= kWaveBins; b++) {
-        HIPCHK_C(hipEventRecord(ctx->ev_bin[b], s));
-        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, ctx->rec + bin_start[b],
-                         ctx->recpre + bin_start[b], h->bin_count[b], row_begin, ctx->tmp, ctx->cnt, s);
+    int cls_n[kMaxTiles][kNumBins] = {};
+    for (int k = 0; k < T && R > 0; k++) {
+        const int *bt0 = ctx->h_bin_tiles + (size_t)tile_index(tb[k]) * kNumBins;
+        const int *bt1 = ctx->h_bin_tiles + (size_t)tile_index(tb[k + 1]) * kNumBins;
+        for (int b = 1; b < kNumBins; b++) {
+            const int n = bt1[b] - bt0[b];
+            cls_n[k][b] = n;
+            if (n <= 0) continue;
+            // the two heaviest classes go to different streams so that every tile keeps the chip full
+            hipStream_t sx = (b == 3 || b == 5 || b == 6) ? sB : s;
+            const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
+            const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
+            HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));
+            if (b <= kWaveBins)
+                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
+                                 ctx->tmp, ctx->cnt, sx);
+            else
+                HIPCHK_C(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
+                                           ctx->tmp, ctx->cnt, sx));
+            HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][1], sx));
+        }
+        HIPCHK_C(hipGetLastError());
+        HIPCHK_C(hipEventRecord(ctx->ev_tile[k][0], sB));
+        HIPCHK_C(hipStreamWaitEvent(s, ctx->ev_tile[k][0], 0));
+        // counts -> row_ptr of this tile, continuing from the previous tile's last entry
+        launch_scan_counts(ctx->cnt + tb[k], tb[k + 1] - tb[k], C->d_row_ptr + tb[k], ctx->partials,
+                           k == 0 ? nullptr : C->d_row_ptr + tb[k], s);
+        HIPCHK_C(hipEventRecord(ctx->ev_tile[k][1], s));
+        HIPCHK_C(hipStreamWaitEvent(sC, ctx->ev_tile[k][1], 0));
+        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, tb[k], tb[k + 1], h->fb[k + 1] - h->fb[k],
+                       C->d_col_idx, sC);
+        HIPCHK_C(hipGetLastError());
     }
-    HIPCHK_C(hipEventRecord(ctx->ev_bin[7], s));
-    HIPCHK_C(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, ctx->rec + bin_start[7],
-                               ctx->recpre + bin_start[7], h->bin_count[7], row_begin, ctx->tmp, ctx->cnt, s));
-    HIPCHK_C(hipGetLastError());
-    HIPCHK_C(hipEventRecord(ctx->ev_bin[8], s));
+    if (R == 0) HIPCHK_C(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
     HIPCHK_C(hipEventRecord(ctx->ev[2], s));
-
-    // ---- stitch: counts -> C.row_ptr, rows squeezed into the exact-size col_idx ---------
-    launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, s);
+    HIPCHK_C(hipEventRecord(ctx->ev_join, sC));
+    HIPCHK_C(hipStreamWaitEvent(s, ctx->ev_join, 0));
     HIPCHK_C(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIPCHK_C(hipStreamSynchronize(s));
-    C->nnz = h->nnzC;
-    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(C->nnz)));
-    launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, R, C->nnz, C->d_col_idx, s);
-    HIPCHK_C(hipGetLastError());
     HIPCHK_C(hipEventRecord(ctx->ev[3], s));
     HIPCHK_C(hipStreamSynchronize(s));
+    C->nnz = h->nnzC;
 #undef HIPCHK_C
 
     bspgemm_stats &st = ctx->stats;
@@ -428,8 +499,14 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     hipEventElapsedTime(&st.ms_symbolic, ctx->ev[0], ctx->ev[1]);
     hipEventElapsedTime(&st.ms_numeric, ctx->ev[1], ctx->ev[2]);
     hipEventElapsedTime(&st.ms_stitch, ctx->ev[2], ctx->ev[3]);
-    for (int b = 1; b < kNumBins; b++)
-        if (h->bin_count[b] > 0) hipEventElapsedTime(&st.ms_bin[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]);
+    st.tiles = T;
+    for (int k = 0; k < T; k++)
+        for (int b = 1; b < kNumBins; b++)
+            if (cls_n[k][b] > 0) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, ctx->ev_cls[k][b][0], ctx->ev_cls[k][b][1]);
+                st.ms_bin[b] += ms;
+            }
     ctx->stats_valid = true;
     *out = C;
     return BSPGEMM_OK;
@@ -469,7 +546,7 @@ extern "C" void bspgemm_result_free(bspgemm_result *C)
     if (!C) return;
     hipSetDevice(C->ctx->device);
     result_release(C->ctx, C->d_row_ptr, result_bytes_rowptr(C->rows));
-    result_release(C->ctx, C->d_col_idx, result_bytes_colidx(C->nnz));
+    result_release(C->ctx, C->d_col_idx, result_bytes_colidx(C->col_cap));
     delete C;
 }
 

@@ -122,18 +122,23 @@ struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B,
 
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
-                                                 const long long *__restrict__ row_ptr, int nrows,
-                                                 long long nnz, int *__restrict__ col_idx)
+                                                 const long long *__restrict__ row_ptr,
+                                                 int row_lo, int row_hi, int *__restrict__ col_idx)
 {
     __shared__ long long rp[kCompactBatch + 1];
     __shared__ long long sh[kCompactBatch];      // source offset - destination offset of the row
     __shared__ int r_first;
     const int tid = threadIdx.x;
-    const long long o0 = (long long)blockIdx.x * kCompactChunk;
-    const long long o1 = (o0 + kCompactChunk < nnz) ? o0 + kCompactChunk : nnz;
+    const long long out_lo = row_ptr[row_lo], out_hi = row_ptr[row_hi];
+    // chunk starts are multiples of 4 outputs so that the 16-B stores stay aligned
+    long long o0 = (out_lo & ~3ll) + (long long)blockIdx.x * kCompactChunk;
+    long long o1 = o0 + kCompactChunk;
+    if (o0 < out_lo) o0 = out_lo;
+    if (o1 > out_hi) o1 = out_hi;
+    if (o0 >= o1) return;                        // uniform: the grid is sized by an upper bound
     if (tid == 0) {
-        // last row r with row_ptr[r] <= o0: it is non-empty and contains output o0
-        int lo = 0, hi = nrows;                  // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
+        // last row r in [row_lo,row_hi) with row_ptr[r] <= o0: non-empty and contains output o0
+        int lo = row_lo, hi = row_hi;            // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (row_ptr[mid] <= o0) lo = mid; else hi = mid;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
     __syncthreads();
     int rbase = r_first;
     while (true) {
-        const int nb = (nrows - rbase < kCompactBatch) ? nrows - rbase : kCompactBatch;   // rows staged
+        const int nb = (row_hi - rbase < kCompactBatch) ? row_hi - rbase : kCompactBatch;   // rows staged
         __syncthreads();
         for (int t = tid; t <= nb; t += 256) rp[t] = row_ptr[rbase + t];
         __syncthreads();
@@ -172,17 +177,17 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                 }
             }
         }
-        if (rp[nb] >= o1 || rbase + nb >= nrows) break;        // uniform: every thread reads the same LDS
+        if (rp[nb] >= o1 || rbase + nb >= row_hi) break;       // uniform: every thread reads the same LDS
         rbase += nb;
     }
 }
 
-void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr, int nrows,
-                    long long nnz, int *col_idx, hipStream_t s)
+void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
+                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s)
 {
-    if (nrows <= 0 || nnz <= 0) return;
-    const int grid = (int)((nnz + kCompactChunk - 1) / kCompactChunk);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, nrows, nnz, col_idx);
+    if (row_hi <= row_lo || max_out <= 0) return;
+    const int grid = (int)((max_out + 3 + kCompactChunk - 1) / kCompactChunk) + 1;
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, row_lo, row_hi, col_idx);
 }
 
 }  // namespace bsp

@@ -45,8 +45,9 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
                          long long *recpre, int *cnt, hipStream_t s);
 
-// exclusive scan of int32 counts into int64 prefix[0..n]
-void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials, hipStream_t s);
+// prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
+void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
+                        const long long *base, hipStream_t s);
 
 // numeric phase, one wave per row (rank-bitmap accumulator)
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
@@ -58,9 +59,11 @@ hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 
-// tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..), nnz = row_ptr[nrows]
+// rows [row_lo,row_hi): tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..).  The output range
+// is read from row_ptr on the device; `max_out` (an upper bound of its length, e.g. the rows'
+// product count) only sizes the grid.
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                    int nrows, long long nnz, int *col_idx, hipStream_t s);
+                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s);
 
 // row_ptr rebasing helper for interior-pointer uploads
 void launch_rebase_i32(int *row_ptr, int n, int base, hipStream_t s);

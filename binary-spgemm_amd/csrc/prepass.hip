@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              const int *__restrict__ bin_count,
                                                              RowRec *__restrict__ rec,
                                                              long long *__restrict__ recpre,
-                                                             int *__restrict__ cnt)
+                                                             int *__restrict__ cnt,
+                                                             const long long *__restrict__ carry_in)
 {
     __shared__ long long wsum[4];
     __shared__ int lcount[kNumBins];
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    long long off = partials[blockIdx.x] + inc - tsum;
+    const long long base0 = carry_in ? *carry_in : 0;     // carry of the rows before this range
+    long long off = base0 + partials[blockIdx.x] + inc - tsum;
     for (int k = 0; k < w; k++) off += wsum[k];
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
         }
         off += v[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = partials[gridDim.x];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = base0 + partials[gridDim.x];
 }
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
@@ -223,20 +225,23 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
     hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles);
     hipLaunchKernelGGL(k_scan_partials, dim3(1 + kNumBins), dim3(1024), 0, s, partials, tiles, bin_tiles, bin_count);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
-                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt);
+                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr);
 }
 
-void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials, hipStream_t s)
+// prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
+// prefix[0]: a range of rows continues the row_ptr of the rows before it
+void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
+                        const long long *base, hipStream_t s)
 {
     if (n <= 0) {
-        hipMemsetAsync(prefix, 0, sizeof(long long), s);
+        if (!base) hipMemsetAsync(prefix, 0, sizeof(long long), s);
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -122,7 +122,8 @@ typedef struct bspgemm_stats {
     float   ms_symbolic;     /* row work + scan + binning                                    */
     float   ms_numeric;      /* accumulate + emit kernels (the dominant kernels)             */
     float   ms_stitch;       /* count scan + compaction into the final col_idx               */
-    float   ms_bin[8];       /* per capacity class: duration of that class's numeric launch  */
+    float   ms_bin[8];       /* per capacity class: summed duration of that class's launches */
+    int     tiles;           /* row super-tiles (each class is launched once per tile)       */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
 
