@@ -5,6 +5,11 @@
 // xb[k] becomes bit k of the LDS bitmap, test-and-set becomes ds_or_b32, and the quickSort of
 // the row (:47) disappears because the bitmap is read out in column order.  Rows this heavy have
 // many duplicate products, so the result is dense enough that scanning the window pays.
+// Gather: the row's A-nonzeros are taken 1024 at a time; their B-row extents (left by the
+// prepass) are scanned into a product-offset table in LDS, and the batch's products are then
+// spread evenly over the 1024 threads -- thread t takes products t, t+1024, ... and finds each
+// one's source row by a 10-step binary search in LDS -- four independent loads in flight per
+// thread, whatever the B-row lengths are.
 // When cols > 2^20 the row's products are re-gathered once per window (B is L2/MALL resident
 // for a hub row: its B rows were just read by the previous window).
 // Also holds the compaction kernels that squeeze the upper-bound-placed rows into C.col_idx.
@@ -15,6 +20,7 @@ namespace bsp {
 
 constexpr int kDenseThreads = 1024;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
+constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
 
 __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
@@ -29,6 +35,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     u64 *bm = reinterpret_cast<u64 *>(lds_raw);
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
     __shared__ int wtot[kDenseThreads / 64];
+    __shared__ int s_pref[kDenseBatch + 1];     // product offset of each source in the batch
+    __shared__ int s_bs[kDenseBatch];           // B.row_ptr of each source
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < wwords; t += kDenseThreads) bm[t] = 0ull;
@@ -40,21 +48,56 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     int *out = tmp + recpre[blockIdx.x];
     const long long W = (long long)wwords * 64;
     const int nwin = (int)(((long long)cols + W - 1) / W);
-    const int group = tid >> 4, sub = tid & 15;                 // 64 groups of 16 lanes
     const int wpt = (wwords + kDenseThreads - 1) / kDenseThreads;
     int total = 0;
 
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
-        for (int jj = a0 + group; jj < a1; jj += kDenseThreads / 16) {
-            const int2 e = ab[jj];
-            const int bs = e.x, be = e.x + e.y;
-            for (int k = bs + sub; k < be; k += 16) {
-                const long long c = (long long)Bcol[k] - lo;
-                if (c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+        for (int ja = a0; ja < a1; ja += kDenseBatch) {
+            // one source (A-nonzero) per thread: extents -> exclusive product offsets
+            int2 e = make_int2(0, 0);
+            if (ja + tid < a1) e = ab[ja + tid];
+            const int sinc = wave_incl_scan(e.y);
+            if (lane == 63) wtot[wave] = sinc;
+            __syncthreads();
+            int soff = sinc - e.y, pb = 0;
+            for (int k = 0; k < kDenseThreads / 64; k++) {
+                const int t = wtot[k];
+                if (k < wave) soff += t;
+                pb += t;
             }
+            s_pref[tid] = soff;
+            s_bs[tid] = e.x;
+            if (tid == 0) s_pref[kDenseBatch] = pb;
+            __syncthreads();
+            // products of the batch, evenly over the threads, 4 independent gathers in flight
+            for (int p0 = tid; p0 < pb; p0 += 4 * kDenseThreads) {
+                int addr[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int p = p0 + u * kDenseThreads;
+                    ok[u] = p < pb;
+                    const int pp = ok[u] ? p : 0;
+                    int lo_s = 0, hi_s = kDenseBatch;          // s_pref[lo_s] <= pp < s_pref[hi_s]
+#pragma unroll
+                    for (int it = 0; it < 10; it++) {
+                        const int mid = (lo_s + hi_s) >> 1;
+                        if (s_pref[mid] <= pp) lo_s = mid; else hi_s = mid;
+                    }
+                    addr[u] = s_bs[lo_s] + (pp - s_pref[lo_s]);
+                }
+                int cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) cv[u] = ok[u] ? Bcol[addr[u]] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const long long c = (long long)cv[u] - lo;
+                    if (ok[u] && c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // each thread owns `wpt` consecutive words: count, block-scan, emit in column order
         const int w0 = tid * wpt;
         const int w1 = (w0 + wpt < wwords) ? w0 + wpt : wwords;

@@ -8,7 +8,7 @@
  *   rmat     : R-MAT, 2^scale vertices, edge_factor*2^scale directed edges,
  *              no vertex permutation                                        (cfg 3, 4, stress)
  *   powerlaw : Pareto(alpha) out-degrees clipped to [1,max_degree] rescaled to the mean,
- *              columns drawn from the same skewed weights                   (cfg 5)
+ *              columns drawn from an independent sample of the same law     (cfg 5)
  * All: duplicates collapsed, col_idx ascending per row, int32 row_ptr.  Randomness is a
  * counter-based SplitMix64 keyed by (seed, element index), so the output does not depend on
  * the number of OpenMP threads.
@@ -178,8 +178,15 @@ bspgemm_status bspgemm_gen_powerlaw(int n, int mean_degree, double alpha, int ma
         if (deg < 1) deg = 1;
         if (deg > max_degree) deg = max_degree;
         start[i + 1] = start[i] + deg;
-        cdf[i + 1] = cdf[i] + w[i] / wsum;
     }
+    /* column popularity: an INDEPENDENT sample of the same Pareto law (a hub column need not be
+     * a hub row), so F = sum |B_j| over A's nonzeros stays ~ nnz * mean degree */
+    double csum = 0;
+    for (int i = 0; i < n; i++) {
+        w[i] = pow(1.0 - rnd01(seed ^ 0x5851F42D4C957F2Dull, (uint64_t)i), -1.0 / (alpha - 1.0));
+        csum += w[i];
+    }
+    for (int i = 0; i < n; i++) cdf[i + 1] = cdf[i] + w[i] / csum;
     const long long m = start[n];
     int *cols = malloc((size_t)(m > 0 ? m : 1) * sizeof(int));
     if (!cols) { free(w); free(cdf); free(start); return BSPGEMM_ERR_ALLOC; }
