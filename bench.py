@@ -91,19 +91,24 @@ def cpu_baseline(rp, ci, n, budget_s=12.0):
         return time.perf_counter() - t, int(crow[-1])
 
     row0 = n // 2
-    pilot_rows = min(cores * 8 * 64, n - row0)
-    pilot_rows -= pilot_rows % (cores * 8)
-    if pilot_rows <= 0:
+    unit = cores * 8                       # keep the decomposition divisible (reference README.md:14)
+    rows = min(unit * 64, n - row0)
+    rows -= rows % unit
+    if rows <= 0:
         return None
-    dt, nnz = run(row0, pilot_rows, max(pilot_rows // (cores * 8), 1))
-    rate = nnz / max(dt, 1e-9)
-    rows = int(min(n - row0, max(pilot_rows, budget_s * rate / max(nnz / pilot_rows, 1e-9))))
-    # keep the reference's int32 nnz safe and the decomposition divisible (README.md:14)
-    rows = min(rows, int(1.5e9 / max(nnz / pilot_rows, 1.0)))
-    rows -= rows % (cores * 8)
-    rows = max(rows, pilot_rows)
-    tblock = rows // (cores * 8)
-    dt, nnz = run(row0, rows, tblock)
+    dt, nnz = run(row0, rows, max(rows // unit, 1))
+    for _ in range(3):                     # grow the sample until it is ~budget_s of CPU work
+        if dt >= 0.6 * budget_s or row0 + rows >= n:
+            break
+        per_row = max(nnz / rows, 1.0)
+        grow = min(budget_s / max(dt, 1e-3), 16.0)
+        new_rows = int(min(n - row0, rows * grow, 1.5e9 / per_row))   # int32 nnz of the reference
+        new_rows -= new_rows % unit
+        if new_rows <= rows:
+            break
+        rows = new_rows
+        dt, nnz = run(row0, rows, rows // unit)
+    tblock = rows // unit
     return {"value": round(nnz / dt / 1e9, 5), "unit": "GNZ/s", "cores": cores, "kind": kind,
             "sample": "rows [%d,%d) of the same matrix (%d output nonzeros), SpGEMM_omp with %d OpenMP "
                       "threads, tBlock=%d, %.2f s" % (row0, row0 + rows, nnz, cores, tblock, dt)}
@@ -200,7 +205,9 @@ def main():
     dom = int(np.argmax(bin_ms))
     sel = bins == dom
     bytes_dom = int(4 * F_row[sel].sum() + 4 * c_row[sel].sum() + 12 * a_row[sel].sum() + 12 * sel.sum())
-    ms_dom = float(bin_ms[dom])
+    tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
+    ms_dom = float(bin_ms[dom]) / tiles
+    bytes_dom //= tiles
     achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
     kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom <= 6 else "k_dense_rows"

@@ -371,3 +371,16 @@ def SpGEMM_hip_mat(Acol, Arow, An, Bcol, Brow, Bm, nnz_c):
     ccol = np.zeros(max(int(nnz_c), 1), dtype=np.int32)
     _chk(lib().SpGEMM_hip_mat(Acol, Arow, An, Bcol, Brow, Bm, ccol, crow), "SpGEMM_hip_mat")
     return crow, ccol[: int(nnz_c)]
+
+
+def SpGEMM_hip_masked(Acol, Arow, An, Bcol, Brow, Bm, Fcol, Frow):
+    """SpGEMM_masked-shaped call (final/SpGEMM_mpi_omp.c:232-235): C = F .* (A*B)."""
+    Acol, Arow, Bcol, Brow, Fcol, Frow = map(_i32, (Acol, Arow, Bcol, Brow, Fcol, Frow))
+    crow = np.zeros(An + 1, dtype=np.int32)
+    csize = C.c_int(max(An, 1))
+    _libc.malloc.restype = C.c_void_p
+    _libc.malloc.argtypes = [C.c_size_t]
+    cc = C.cast(_libc.malloc(csize.value * 4), C.POINTER(C.c_int))
+    st = lib().SpGEMM_hip_masked(Acol, Arow, An, Bcol, Brow, Bm, Fcol, Frow, C.byref(cc), crow, C.byref(csize))
+    _chk(st, "SpGEMM_hip_masked")
+    return crow, _take_i32(cc, crow[-1])

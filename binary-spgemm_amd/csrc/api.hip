@@ -369,13 +369,14 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
     return BSPGEMM_OK;
 }
 
-extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_matrix *A,
-                                           const bspgemm_matrix *B, int row_begin, int row_end,
-                                           bspgemm_result **out)
+static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                    const bspgemm_matrix *B, const bspgemm_matrix *Fm,
+                                    int row_begin, int row_end, bspgemm_result **out)
 {
     if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
     *out = nullptr;
     if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
+    if (Fm && (Fm->ctx != ctx || Fm->rows < row_end)) return FAIL(BSPGEMM_ERR_INVALID, "mask has fewer rows than A / wrong context");
     if (bspgemm_status st = use_device(ctx)) return st;
     const int R = row_end - row_begin;
     hipStream_t s = ctx->stream;
@@ -402,7 +403,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     // Row super-tiles (multiples of the 2048-row scan tile).  Tile k's rows are accumulated, their
     // counts scanned, and their compaction runs on its own stream while tile k+1 is accumulated.
     const int scan_tiles = (R + 2047) / 2048;
-    int T = 2;
+    int T = 1;                                         // BSPGEMM_TILES > 1 turns the pipelining on
     if (const char *e = getenv("BSPGEMM_TILES")) T = atoi(e);
     if (T < 1) T = 1;
     if (T > kMaxTiles) T = kMaxTiles;
@@ -453,11 +454,14 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
             cls_n[k][b] = n;
             if (n <= 0) continue;
             // the two heaviest classes go to different streams so that every tile keeps the chip full
-            hipStream_t sx = (b == 3 || b == 5 || b == 6) ? sB : s;
+            hipStream_t sx = (T > 1 && (b == 3 || b == 5 || b == 6)) ? sB : s;
             const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
             const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
             HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));
-            if (b <= kWaveBins)
+            if (Fm)
+                HIPCHK_C(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
+                                                  ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
+            else if (b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
                                  ctx->tmp, ctx->cnt, sx);
             else
@@ -512,12 +516,25 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     return BSPGEMM_OK;
 }
 
-extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *, const bspgemm_matrix *,
-                                                  const bspgemm_matrix *, const bspgemm_matrix *, int, int,
-                                                  bspgemm_result **out)
+extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                           const bspgemm_matrix *B, int row_begin, int row_end,
+                                           bspgemm_result **out)
 {
-    if (out) *out = nullptr;
-    return FAIL(BSPGEMM_ERR_INVALID, "masked product: not built yet (SURVEY.md 8f row f3)");
+    return multiply_impl(ctx, A, B, nullptr, row_begin, row_end, out);
+}
+
+// First implementation of the masked product: every non-empty row goes through the dense-window
+// kernel with a second (kept-bits) bitmap.  Correct for any shape; a mask-first rank-bitmap path
+// for short rows is the planned fast path.
+extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                                  const bspgemm_matrix *B, const bspgemm_matrix *F,
+                                                  int row_begin, int row_end, bspgemm_result **out)
+{
+    if (!F) {
+        if (out) *out = nullptr;
+        return FAIL(BSPGEMM_ERR_INVALID, "mask is NULL");
+    }
+    return multiply_impl(ctx, A, B, F, row_begin, row_end, out);
 }
 
 extern "C" int bspgemm_result_rows(const bspgemm_result *C) { return C ? C->rows : 0; }
@@ -643,7 +660,8 @@ static int dropin_fail(const char *fn, bspgemm_status st)
 // mode 2: caller's buffer is exact (SpGEMM_mat)
 static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r1,
                                  const int *Bcol, const int *Brow, int Bm,
-                                 int **Ccol, int *Crow, int *Csize, int mode)
+                                 int **Ccol, int *Crow, int *Csize, int mode,
+                                 const int *Fcol = nullptr, const int *Frow = nullptr)
 {
     if (!Acol || !Arow || !Bcol || !Brow || !Crow || !Ccol || r0 < 0 || r1 < r0 || Bm < 0)
         return FAIL(BSPGEMM_ERR_INVALID, "drop-in arguments");
@@ -654,11 +672,12 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
     // B's row count is implicit in the reference (never passed): 1 + the largest column of A used
     int brows = 0;
     for (int jj = Arow[r0]; jj < Arow[r1]; jj++) if (Acol[jj] >= brows) brows = Acol[jj] + 1;
-    bspgemm_matrix *A = nullptr, *B = nullptr;
+    bspgemm_matrix *A = nullptr, *B = nullptr, *Fm = nullptr;
     bspgemm_result *C = nullptr;
     bspgemm_status st = bspgemm_matrix_upload(ctx, rows, brows, Arow + r0, Acol, &A);
     if (!st) st = bspgemm_matrix_upload(ctx, brows, Bm, Brow, Bcol, &B);
-    if (!st) st = bspgemm_multiply(ctx, A, B, 0, rows, &C);
+    if (!st && Frow) st = bspgemm_matrix_upload(ctx, rows, Bm, Frow + r0, Fcol, &Fm);
+    if (!st) st = Fm ? bspgemm_multiply_masked(ctx, A, B, Fm, 0, rows, &C) : bspgemm_multiply(ctx, A, B, 0, rows, &C);
     if (!st) {
         const long long nnz = bspgemm_result_nnz(C);
         if (nnz > INT_MAX) {
@@ -695,6 +714,7 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
     bspgemm_result_free(C);
     bspgemm_matrix_free(A);
     bspgemm_matrix_free(B);
+    bspgemm_matrix_free(Fm);
     return st;
 }
 
@@ -723,10 +743,12 @@ extern "C" int SpGEMM_hip_mat(int *Acol, int *Arow, int An, int *Bcol, int *Brow
     return st ? dropin_fail("SpGEMM_hip_mat", st) : 0;
 }
 
-extern "C" int SpGEMM_hip_masked(int *, int *, int, int *, int *, int, int *, int *, int **Ccol, int *, int *)
+extern "C" int SpGEMM_hip_masked(int *Acol, int *Arow, int An, int *Bcol, int *Brow, int Bm,
+                                 int *Fcol, int *Frow, int **Ccol, int *Crow, int *Csize)
 {
-    if (Ccol) *Ccol = nullptr;
-    return dropin_fail("SpGEMM_hip_masked", FAIL(BSPGEMM_ERR_INVALID, "masked product: not built yet"));
+    if (!Fcol || !Frow) return dropin_fail("SpGEMM_hip_masked", FAIL(BSPGEMM_ERR_INVALID, "mask is NULL"));
+    bspgemm_status st = dropin_run(Acol, Arow, 0, An, Bcol, Brow, Bm, Ccol, Crow, Csize, 1, Fcol, Frow);
+    return st ? dropin_fail("SpGEMM_hip_masked", st) : 0;
 }
 
 // ------------------------------------------------------------------ multi-GPU stitch -----

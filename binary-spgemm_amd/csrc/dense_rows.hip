@@ -22,6 +22,11 @@ constexpr int kDenseThreads = 1024;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
 constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
 
+// MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
+// its flag array so that only columns of F's row can be appended (:253-255); here the window
+// holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
+// set in P is set in K, and K is what gets read out.
+template <bool MASKED>
 __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
@@ -29,17 +34,21 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
                                                               const long long *__restrict__ recpre,
                                                               int row_begin,
                                                               int *__restrict__ tmp,
-                                                              int *__restrict__ cnt)
+                                                              int *__restrict__ cnt,
+                                                              const int *__restrict__ Frow,
+                                                              const int *__restrict__ Fcol)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u64 *bm = reinterpret_cast<u64 *>(lds_raw);
+    u64 *bmP = reinterpret_cast<u64 *>(lds_raw);                       // products
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
+    u64 *bm = MASKED ? bmP + wwords : bmP;                             // what is read out (K or P)
+    u32 *bmK32 = reinterpret_cast<u32 *>(bm);
     __shared__ int wtot[kDenseThreads / 64];
     __shared__ int s_pref[kDenseBatch + 1];     // product offset of each source in the batch
     __shared__ int s_bs[kDenseBatch];           // B.row_ptr of each source
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int t = tid; t < wwords; t += kDenseThreads) bm[t] = 0ull;
+    for (int t = tid; t < (MASKED ? 2 * wwords : wwords); t += kDenseThreads) bmP[t] = 0ull;
     __syncthreads();
 
     const RowRec q = rec[blockIdx.x];
@@ -98,6 +107,17 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
             }
             __syncthreads();
         }
+        if (MASKED) {
+            // keep the product bits that F's row admits, then wipe P for the next window / row
+            const int f0 = Frow[i], f1 = Frow[i + 1];
+            for (int k = f0 + tid; k < f1; k += kDenseThreads) {
+                const long long c = (long long)Fcol[k] - lo;
+                if (c >= 0 && c < W && ((bm32[c >> 5] >> (c & 31)) & 1u)) atomicOr(&bmK32[c >> 5], 1u << (c & 31));
+            }
+            __syncthreads();
+            for (int t = tid; t < wwords; t += kDenseThreads) bmP[t] = 0ull;
+            __syncthreads();
+        }
         // each thread owns `wpt` consecutive words: count, block-scan, emit in column order
         const int w0 = tid * wpt;
         const int w1 = (w0 + wpt < wwords) ? w0 + wpt : wwords;
@@ -128,25 +148,41 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     if (tid == 0) cnt[i - row_begin] = total;
 }
 
+template <bool MASKED>
+static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, const RowRec *rec,
+                                    const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt,
+                                    const int *Frow, const int *Fcol, hipStream_t s)
+{
+    if (nrows <= 0) return hipSuccess;
+    const long long max_words = MASKED ? kDenseMaxWords / 2 : kDenseMaxWords;   // two bitmaps share the window
+    long long words = ((long long)cols + 63) / 64;
+    if (words > max_words) words = max_words;
+    if (words < 1) words = 1;
+    const int bytes = (int)words * 8 * (MASKED ? 2 : 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_rows<MASKED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_dense_rows<MASKED>), dim3(nrows), dim3(kDenseThreads), bytes, s, ab, Bcol,
+                       cols, (int)words, rec, recpre, row_begin, tmp, cnt, Frow, Fcol);
+    return hipGetLastError();
+}
+
 hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s)
 {
-    if (nrows <= 0) return hipSuccess;
-    long long words = ((long long)cols + 63) / 64;
-    if (words > kDenseMaxWords) words = kDenseMaxWords;
-    if (words < 1) words = 1;
-    const int bytes = (int)words * 8;
-    static int attr_set_for = 0;
-    if (bytes > attr_set_for) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_rows),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set_for = 128 * 1024;
-    }
-    hipLaunchKernelGGL(k_dense_rows, dim3(nrows), dim3(kDenseThreads), bytes, s, ab, Bcol,
-                       cols, (int)words, rec, recpre, row_begin, tmp, cnt);
-    return hipGetLastError();
+    return launch_dense_impl<false>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
+}
+
+hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
+                                    const RowRec *rec, const long long *recpre, int nrows, int row_begin,
+                                    int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s)
+{
+    return launch_dense_impl<true>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
 }
 
 // ---------------------------------------------------------------------------------------

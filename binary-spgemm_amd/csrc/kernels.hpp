@@ -59,6 +59,12 @@ hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 
+// masked variant: C = F .* (A*B); every non-empty row goes through the window kernel, which
+// keeps only the product bits that F's row (absolute row id, F.row_ptr/F.col_idx) admits
+hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
+                                    const RowRec *rec, const long long *recpre, int nrows, int row_begin,
+                                    int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s);
+
 // rows [row_lo,row_hi): tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..).  The output range
 // is read from row_ptr on the device; `max_out` (an upper bound of its length, e.g. the rows'
 // product count) only sizes the grid.

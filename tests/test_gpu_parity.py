@@ -188,6 +188,42 @@ def test_empty_and_degenerate(ctx):
         ctx.multiply(A, A, 0, n + 1)
 
 
+# ---------------------------------------------------------------- masked product ----------
+def test_masked_golden_and_dropin(ctx):
+    """C = F .* (A*B) against the reference's SpGEMM_masked golden (final/SpGEMM_mpi_omp.c:232-288)"""
+    g = np.load(os.path.join(GOLDEN, "masked_n512.npz"), allow_pickle=False)
+    n = int(g["n"])
+    A = ctx.upload(g["a_rp"], g["a_ci"], n)
+    F = ctx.upload(g["f_rp"], g["f_ci"], n)
+    C = ctx.multiply_masked(A, A, F)
+    crp, cci = C.download()
+    assert_same(crp, cci, g["c_rp"], g["c_ci"])
+    crow, ccol = bspgemm.SpGEMM_hip_masked(g["a_ci"], g["a_rp"], n, g["a_ci"], g["a_rp"], n, g["f_ci"], g["f_rp"])
+    assert_same(crow, ccol, g["c_rp"], g["c_ci"])
+
+
+@pytest.mark.parametrize("ncols", [5000, 700_000], ids=["one_window", "two_windows"])
+def test_masked_against_oracle(ctx, ncols):
+    """rectangular A != B, mask rows of mixed length (empty, short, dense), row sub-range"""
+    a_rp, a_ci = gen.uniform_rect(900, 700, 9, seed=801)
+    rng = np.random.default_rng(802)
+    rows = np.repeat(np.arange(700), 40)
+    b_rp, b_ci = gen._csr_from_pairs(rows, rng.integers(0, ncols, size=rows.size), 700)
+    frows = np.concatenate([np.repeat(np.arange(0, 900, 3), 300), np.repeat(np.arange(1, 900, 3), 5), np.full(ncols // 2, 7)])
+    fcols = np.concatenate([rng.integers(0, ncols, size=frows.size - ncols // 2), np.arange(0, ncols // 2 * 2, 2)])
+    f_rp, f_ci = gen._csr_from_pairs(frows, fcols, 900)
+    erp, eci = O.spgemm_masked(a_rp, a_ci, b_rp, b_ci, ncols, f_rp, f_ci)
+    A = ctx.upload(a_rp, a_ci, 700)
+    B = ctx.upload(b_rp, b_ci, ncols)
+    F = ctx.upload(f_rp, f_ci, ncols)
+    C = ctx.multiply_masked(A, B, F)
+    crp, cci = C.download()
+    assert_same(crp, cci, erp, eci)
+    C2 = ctx.multiply_masked(A, B, F, 100, 433)                 # interior rows keep F aligned by row id
+    r2, c2 = C2.download()
+    assert np.array_equal(r2, erp[100:434] - erp[100]) and np.array_equal(c2, eci[erp[100]:erp[433]])
+
+
 # ---------------------------------------------------------------- (3) properties at size --
 def _check_wellformed(rp, ci, ncols):
     assert rp[0] == 0 and rp[-1] == ci.size and np.all(np.diff(rp) >= 0)
