@@ -6,16 +6,10 @@
 
 namespace bsp {
 
-// capacity classes of a row by its product count F_i:
-//   0            : empty
-//   1..10        : one wavefront per row, capacity 64*kWaveChunks[b] products (64 ... 2048 in
-//                  steps of ~1.5x: the per-row fixed costs and the LDS footprint follow the capacity)
-//   kDenseBin=11 : dense-window rows (F_i > 2048)
-constexpr int kWaveBins = 10;
-constexpr int kNumBins = kWaveBins + 2;
-constexpr int kDenseBin = kNumBins - 1;
-constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
-constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
+// one-wave-per-row capacity classes: bin b (1..6) holds rows with F_i <= 64 << (b-1)
+constexpr int kNumBins = 8;             // 0 empty, 1..6 wave rows, 7 dense-window rows
+constexpr int kWaveBins = 6;
+constexpr int kMaxWaveCap = 64 << (kWaveBins - 1);   // 2048 products
 constexpr int kRowsPerWave = 16;         // consecutive list entries handled by one wave
 
 constexpr int kWaveTopWords = 256;      // 32-bit words of the directly addressed top bitmap

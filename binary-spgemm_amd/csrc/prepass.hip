@@ -66,16 +66,14 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;   // 2048 values per workgroup
 
-// capacity class of a row with F products (see kernels.hpp)
+// capacity class of a row with F products: 0 empty, 1..6 one wave (64<<(b-1)), 7 dense window
 __device__ __forceinline__ int bin_of(long long F)
 {
     if (F <= 0) return 0;
-    if (F > kMaxWaveCap) return kDenseBin;
+    if (F > kMaxWaveCap) return 7;
     const int f = (int)F;
-    int b = 1;
-#pragma unroll
-    for (int k = 1; k < kWaveBins; k++) b += (f > 64 * kWaveChunks[k]) ? 1 : 0;
-    return b;
+    const int hb = 32 - __clz(f - 1);          // bits needed for f-1 (0 for f == 1)
+    return hb <= 6 ? 1 : hb - 5;
 }
 
 template <typename T, bool BIN>

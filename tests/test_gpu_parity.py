@@ -114,7 +114,7 @@ def test_against_oracle(ctx, name):
 
 
 def test_every_capacity_class_is_exercised(ctx):
-    """rows with F_i just below/above each class boundary 64,128,192,...,2048 and beyond"""
+    """rows with F_i just below/above each class boundary 64,128,...,2048 and beyond"""
     n = 6000
     rng = np.random.default_rng(301)
     # B: row j has (j % 97) + 1 entries; A rows pick B rows so that F_i sweeps 1..4000
@@ -122,8 +122,8 @@ def test_every_capacity_class_is_exercised(ctx):
     b_cols = rng.integers(0, n, size=b_rows.size)
     b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, n)
     blen = np.diff(b_rp)
-    targets = [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512, 513,
-               767, 768, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2048, 2049, 3000, 4000] * 6
+    targets = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025,
+               2047, 2048, 2049, 3000, 4000] * 8
     a_rows, a_cols = [], []
     for i, t in enumerate(targets):
         acc = 0
@@ -168,7 +168,7 @@ def test_dense_rows_several_windows(ctx):
     erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
     crp, cci, st = hip_product(ctx, a_rp, a_ci, nb, b_rp, b_ci, ncols)
     assert_same(crp, cci, erp, eci)
-    assert st["rows_per_bin"][-1] >= 3
+    assert st["rows_per_bin"][7] >= 3
 
 
 def test_empty_and_degenerate(ctx):
