@@ -34,7 +34,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 RMAT_MILD = (0.30, 0.25, 0.25)  # d = 0.20
-BIN_CAPS = [0, 64, 128, 256, 512, 1024, 2048]
+BIN_CAPS = [0, 64, 128, 256, 512, 1024, 2048]          # csrc/kernels.hpp: one-wave capacity classes
+DENSE_BIN = len(BIN_CAPS)                               # class of the dense-window rows
 
 
 def log(rank, *a):
@@ -211,8 +212,25 @@ def main():
     achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
     kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom <= 6 else "k_dense_rows"
+    # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process,
+    # so the committed rocprofv3 --pmc result of this very command is quoted when the workload is
+    # the profiled one (tools/pmc_run.sh -> profiles/*_pmc_traffic.json); otherwise null.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+            prof = json.load(open(path))
+            key = ("bsp::k_wave_rows<%d, %d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
+            if prof.get("workload") == wname and world == 1 and tiles == 1 and key in prof.get("kernels", {}):
+                k = prof["kernels"][key]
+                traffic = int(k["fetch_bytes"] + k["write_bytes"])
+                traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE, uncorrected)"
+                break
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": kernel,
                 "bytes_per_launch": bytes_dom, "ms_per_launch": round(ms_dom, 4),
                 "launch_rows": int(sel.sum()), "launch_products": int(F_row[sel].sum())}
 
