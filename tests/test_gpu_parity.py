@@ -285,6 +285,35 @@ def test_rmat_scale20_properties_and_sampled_rows(ctx):
         assert np.array_equal(cci[crp[r0]:crp[r0 + 4096]], eci)
 
 
+def test_more_than_int32_output_nonzeros(ctx):
+    """nnz(C) > 2^31-1 (what BASELINE configs 4 and 5 need and the reference's `int` counters cannot
+    hold, final/SpGEMM_mpi_omp.c:20,111,177): int64 row_ptr end to end, sampled rows exact, and the
+    int32 drop-in REFUSES instead of wrapping."""
+    rp, ci, n = bspgemm.gen_uniform(1 << 22, 23, seed=5)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A)
+    assert C.nnz > 2**31 - 1, C.nnz
+    crp, _ = C.download(col_idx=False)
+    assert crp[-1] == C.nnz and np.all(np.diff(crp) >= 0)
+    st = ctx.stats()
+    assert st["products"] == O.count_products(rp, ci, rp) and st["nnz_c"] == C.nnz
+    # rows around the 2^31 boundary of the output and at both ends, straight from the device buffer
+    import torch
+    from bspgemm import dist as bdist
+    dev = torch.device("cuda", 0)
+    cols = bdist.device_tensor(C.col_idx_device, C.nnz, torch.int32, dev)
+    r_mid = int(np.searchsorted(crp, 2**31)) - 2
+    for r0 in (0, r_mid, n - 8):
+        erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0, r0 + 8)
+        assert np.array_equal(crp[r0:r0 + 9] - crp[r0], erp)
+        got = cols[int(crp[r0]): int(crp[r0 + 8])].cpu().numpy()
+        assert np.array_equal(got, eci)
+    C.free()
+    with pytest.raises(bspgemm.BspgemmError) as e:
+        bspgemm.SpGEMM_hip(ci, rp, n, ci, rp, n)
+    assert e.value.status == 5          # BSPGEMM_ERR_OVERFLOW
+
+
 def test_boolean_closure_is_idempotent(ctx):
     """(I + A)^k reaches a fixpoint T with T*T == T (the motivating use)"""
     n = 600
