@@ -43,6 +43,7 @@ EXPORTS = [
     "bspgemm_comm_unique_id", "bspgemm_comm_create", "bspgemm_comm_destroy", "bspgemm_comm_stitch_row_ptr",
     "bspgemm_readCOO", "bspgemm_write_mtx", "bspgemm_write_result_mtx", "bspgemm_csr_equal",
     "bspgemm_csr_equal64", "bspgemm_gen_uniform", "bspgemm_gen_rmat", "bspgemm_gen_powerlaw",
+    "bspgemm_matrix_from_result", "bspgemm_closure",
 ]
 
 
@@ -111,6 +112,8 @@ def lib():
     L.bspgemm_result_download.argtypes = [VP, VP, VP, VP]
     L.bspgemm_result_free.argtypes = [VP]
     L.bspgemm_result_free.restype = None
+    L.bspgemm_matrix_from_result.argtypes = [VP, VP, C.c_int, PVP]
+    L.bspgemm_closure.argtypes = [VP, VP, C.c_int, PVP, C.POINTER(C.c_int)]
     L.bspgemm_row_work_prefix.argtypes = [VP, VP, VP, _I64P]
     L.bspgemm_partition_rows.argtypes = [VP, VP, VP, C.c_int, _I32P]
     L.bspgemm_last_stats.argtypes = [VP, C.POINTER(Stats)]
@@ -168,7 +171,8 @@ def readCOO(path):
     m, n, nz = C.c_uint32(), C.c_uint32(), C.c_uint32()
     _chk(L.bspgemm_readCOO(os.fsencode(path), C.byref(rp), C.byref(ci), C.byref(m), C.byref(n), C.byref(nz)),
          "readCOO(%s)" % path)
-    return _take_i32(rp, m.value + 1), _take_i32(ci, nz.value), m.value, n.value
+    # the CSR has one row per FILE COLUMN (N); the reference only ever reads square files (n = M)
+    return _take_i32(rp, n.value + 1), _take_i32(ci, nz.value), m.value, n.value
 
 
 def write_mtx(path, row_ptr, col_idx, cols=None):
@@ -270,6 +274,17 @@ class Context:
         _chk(lib().bspgemm_multiply_masked(self._h, A._h, B._h, F._h, row_begin, row_end, C.byref(r)),
              "bspgemm_multiply_masked")
         return Result(self, r)
+
+    def matrix_from_result(self, result, cols):
+        m = C.c_void_p()
+        _chk(lib().bspgemm_matrix_from_result(self._h, result._h, cols, C.byref(m)), "matrix_from_result")
+        return Matrix(self, m, keep=None)
+
+    def closure(self, A, max_iter=64):
+        """reflexive-transitive closure by repeated squaring; returns (Result, products computed)"""
+        r, it = C.c_void_p(), C.c_int()
+        _chk(lib().bspgemm_closure(self._h, A._h, max_iter, C.byref(r), C.byref(it)), "bspgemm_closure")
+        return Result(self, r), it.value
 
     def stats(self):
         s = Stats()

@@ -574,6 +574,67 @@ extern "C" bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm
     return BSPGEMM_OK;
 }
 
+// ------------------------------------------------------------------ products as operands -
+extern "C" bspgemm_status bspgemm_matrix_from_result(bspgemm_context *ctx, const bspgemm_result *C, int cols,
+                                                     bspgemm_matrix **out)
+{
+    if (!ctx || !C || !out || cols < 0 || C->ctx != ctx) return FAIL(BSPGEMM_ERR_INVALID, "matrix_from_result");
+    *out = nullptr;
+    if (C->nnz > INT_MAX) return FAIL(BSPGEMM_ERR_OVERFLOW, "product has more than INT_MAX nonzeros: not usable as an int32 operand");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    bspgemm_matrix *m = new (std::nothrow) bspgemm_matrix{ctx, C->rows, cols, C->nnz, nullptr, nullptr, true};
+    if (!m) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)C->rows + 1) * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int)));
+    launch_narrow_row_ptr(C->d_row_ptr, m->d_row_ptr, C->rows + 1, ctx->stream);
+    if (C->nnz > 0)
+        HIPCHK(hipMemcpyAsync(m->d_col_idx, C->d_col_idx, (size_t)C->nnz * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = m;
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_closure(bspgemm_context *ctx, const bspgemm_matrix *A, int max_iter,
+                                          bspgemm_result **T, int *iterations)
+{
+    if (!ctx || !A || !T || A->ctx != ctx || A->rows != A->cols) return FAIL(BSPGEMM_ERR_INVALID, "closure needs a square matrix");
+    *T = nullptr;
+    if (iterations) *iterations = 0;
+    if (max_iter < 1) max_iter = 1;
+    if (A->nnz + (long long)A->rows > INT_MAX) return FAIL(BSPGEMM_ERR_OVERFLOW, "A or I exceeds int32 nonzeros");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int n = A->rows;
+    bspgemm_matrix *cur = new (std::nothrow) bspgemm_matrix{ctx, n, n, A->nnz + n, nullptr, nullptr, true};
+    if (!cur) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&cur->d_row_ptr), ((size_t)n + 1) * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&cur->d_col_idx), ((size_t)cur->nnz + 1) * sizeof(int)));
+    launch_add_diagonal(A->d_row_ptr, A->d_col_idx, n, cur->d_row_ptr, cur->d_col_idx, ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    long long prev_nnz = -1;      // nnz of the deduplicated T(k); unknown for T0 (may hold duplicates)
+    bspgemm_result *C = nullptr;
+    bspgemm_status st = BSPGEMM_OK;
+    for (int it = 0; it < max_iter; it++) {
+        bspgemm_result *next = nullptr;
+        st = bspgemm_multiply(ctx, cur, cur, 0, n, &next);
+        if (st) break;
+        if (iterations) *iterations = it + 1;
+        bspgemm_result_free(C);
+        C = next;
+        if (C->nnz == prev_nnz) break;                  // T*T == T: fixpoint (T contains I, so T <= T*T)
+        prev_nnz = C->nnz;
+        if (it + 1 == max_iter) break;
+        bspgemm_matrix *nm = nullptr;
+        st = bspgemm_matrix_from_result(ctx, C, n, &nm);
+        if (st) break;
+        bspgemm_matrix_free(cur);
+        cur = nm;
+    }
+    bspgemm_matrix_free(cur);
+    if (st) { bspgemm_result_free(C); return st; }
+    *T = C;
+    return BSPGEMM_OK;
+}
+
 // ------------------------------------------------------------------ sharding helper ------
 extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bspgemm_matrix *A,
                                                   const bspgemm_matrix *B, int64_t *prefix_host)

@@ -71,6 +71,11 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
                     int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s);
 
+// int64 row_ptr -> int32 (operand form of a product)
+void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);
+// T = A or I as CSR: row i gets column i appended (duplicates are legal in operands)
+void launch_add_diagonal(const int *Arow, const int *Acol, int n, int *Trow, int *Tcol, hipStream_t s);
+
 // row_ptr rebasing helper for interior-pointer uploads
 void launch_rebase_i32(int *row_ptr, int n, int base, hipStream_t s);
 

@@ -256,4 +256,39 @@ void launch_rebase_i32(int *row_ptr, int n, int base, hipStream_t s)
     hipLaunchKernelGGL(k_rebase_i32, dim3((n + 255) / 256), dim3(256), 0, s, row_ptr, n, base);
 }
 
+__global__ void k_narrow_row_ptr(const long long *__restrict__ src, int *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int)src[i];
+}
+void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_narrow_row_ptr, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+
+// 8 lanes per row copy the row shifted by its index; lane 0 appends the diagonal
+__global__ __launch_bounds__(256) void k_add_diagonal(const int *__restrict__ Arow, const int *__restrict__ Acol,
+                                                      int n, int *__restrict__ Trow, int *__restrict__ Tcol)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(gid >> 3), sub = (int)(gid & 7);
+    if (r > n) return;
+    if (r == n) {
+        if (sub == 0) Trow[n] = Arow[n] + n;
+        return;
+    }
+    const int a0 = Arow[r], a1 = Arow[r + 1], t0 = a0 + r;
+    for (int k = a0 + sub; k < a1; k += 8) Tcol[t0 + (k - a0)] = Acol[k];
+    if (sub == 0) {
+        Tcol[t0 + (a1 - a0)] = r;
+        Trow[r] = t0;
+    }
+}
+void launch_add_diagonal(const int *Arow, const int *Acol, int n, int *Trow, int *Tcol, hipStream_t s)
+{
+    const long long threads = ((long long)n + 1) * 8;
+    hipLaunchKernelGGL(k_add_diagonal, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, Arow, Acol, n, Trow, Tcol);
+}
+
 }  // namespace bsp

@@ -146,7 +146,8 @@ bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
     return BSPGEMM_OK;
 }
 
-/* CSR (r, c) is written as the file entry "c+1 r+1": readCOO's transposition maps it back. */
+/* CSR (r, c) is written as the file entry "c+1 r+1": readCOO's transposition maps it back.
+ * The file's matrix is therefore cols x rows (header "cols rows nnz"); square in every reference use. */
 static bspgemm_status write_impl(const char *path, int rows, int cols, const int *rp32,
                                  const int64_t *rp64, const int *col_idx)
 {
@@ -156,7 +157,7 @@ static bspgemm_status write_impl(const char *path, int rows, int cols, const int
     static char big[1 << 20];
     setvbuf(f, big, _IOFBF, sizeof big);
     const long long nnz = rp32 ? rp32[rows] - rp32[0] : rp64[rows] - rp64[0];
-    fprintf(f, "%%%%MatrixMarket matrix coordinate pattern general\n%d %d %lld\n", rows, cols, nnz);
+    fprintf(f, "%%%%MatrixMarket matrix coordinate pattern general\n%d %d %lld\n", cols, rows, nnz);
     for (int r = 0; r < rows; r++) {
         const long long b = rp32 ? rp32[r] : rp64[r], e = rp32 ? rp32[r + 1] : rp64[r + 1];
         for (long long k = b; k < e; k++) fprintf(f, "%d %d\n", col_idx[k] + 1, r + 1);

@@ -15,6 +15,13 @@
  * host gathers; e2e_fastest adds the copy of C to host memory.  nnz(C) is printed as a 64-bit
  * integer (the reference's %d overflows above 2^31-1).
  *
+ * Two optional positionals widen the reference's always-A*A driver:
+ *     SpGEMM_hip  A.mtx  tBlock  threads  times  [B.mtx  [C_out.mtx]]
+ * computes the FILE-orientation product A*B of two (possibly rectangular) pattern files and, when
+ * a third path is given, writes C as `matrix coordinate pattern general`.  readCOO keeps every
+ * file transposed in memory (final/utils.c:77), and (A*B)^T = B^T * A^T, so the in-memory
+ * product is loaded(B) * loaded(A); the writer transposes back.  "-" as B.mtx means A.
+ *
  * With -DBSPGEMM_WITH_MPI: one MPI rank per GPU (rank r -> device r mod #devices), every rank
  * reads the whole file (B replicated, like :309), rows are cut at equal work, C.row_ptr is
  * stitched over RCCL (unique id broadcast with MPI_Bcast); col_idx stays on the GPUs.
@@ -60,7 +67,7 @@ int main(int argc, char **argv)
     MPI_Comm_size(MPI_COMM_WORLD, &numtasks);
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
 #endif
-    if (argc != 5) {                                                     /* :357-360 */
+    if (argc < 5 || argc > 7) {                                          /* :357-360 (+ optional B, C_out) */
         printf("usage: mpirun  -n  numtasks  SpGEMM_mpi_omp  path-to-matrix  threadslice_size  number_of_threads  times_to_run\n");
         exit(1);
     }
@@ -70,7 +77,7 @@ int main(int argc, char **argv)
     if (times < 1) times = 1;
 
     uint32_t *Arow, *Acol, An, Am, Annz;
-    bspgemm_status st = bspgemm_readCOO(argv[1], &Arow, &Acol, &An, &Am, &Annz);
+    bspgemm_status st = bspgemm_readCOO(argv[1], &Arow, &Acol, &An, &Am, &Annz);   /* An = M, Am = N */
     if (st == BSPGEMM_ERR_FORMAT) printf("Could not process Matrix Market banner.\n");   /* utils.c:57 */
     if (st != BSPGEMM_OK) exit(1);                                                        /* utils.c:55,58,61 */
 
@@ -81,11 +88,25 @@ int main(int argc, char **argv)
     if (st == BSPGEMM_ERR_INVALID && !devenv) st = bspgemm_create(0, &ctx);   /* fewer devices than ranks */
     CHECK(st, "bspgemm_create");
 
-    bspgemm_matrix *A;
-    CHECK(bspgemm_matrix_upload(ctx, (int)An, (int)An, (const int *)Arow, (const int *)Acol, &A), "upload");
+    /* in-memory (transposed) shapes: loaded(X) has X.N rows and X.M columns */
+    const int a_rows = (int)Am, a_cols = (int)An;
+    bspgemm_matrix *A, *L = NULL;                   /* L = left operand of the in-memory product */
+    CHECK(bspgemm_matrix_upload(ctx, a_rows, a_cols, (const int *)Arow, (const int *)Acol, &A), "upload");
+    int c_cols = a_cols;
+    if (argc >= 6 && strcmp(argv[5], "-") != 0) {
+        uint32_t *Brow, *Bcol, Bn, Bm, Bnnz;
+        st = bspgemm_readCOO(argv[5], &Brow, &Bcol, &Bn, &Bm, &Bnnz);
+        if (st == BSPGEMM_ERR_FORMAT) printf("Could not process Matrix Market banner.\n");
+        if (st != BSPGEMM_OK) exit(1);
+        if ((int)Bn != a_rows) { fprintf(stderr, "inner dimensions differ: A is %ux%u, B is %ux%u\n", An, Am, Bn, Bm); exit(1); }
+        CHECK(bspgemm_matrix_upload(ctx, (int)Bm, (int)Bn, (const int *)Brow, (const int *)Bcol, &L), "upload B");
+        free(Brow); free(Bcol);
+    }
+    bspgemm_matrix *Lhs = L ? L : A;                 /* loaded(B) * loaded(A), or A*A like :322 */
+    const int c_rows = bspgemm_matrix_rows(Lhs);
 
     int *bounds = malloc(((size_t)numtasks + 1) * sizeof(int));
-    CHECK(bspgemm_partition_rows(ctx, A, A, numtasks, bounds), "partition");
+    CHECK(bspgemm_partition_rows(ctx, Lhs, A, numtasks, bounds), "partition");
     const int r0 = bounds[rank], r1 = bounds[rank + 1];
 
 #ifdef BSPGEMM_WITH_MPI
@@ -106,13 +127,14 @@ int main(int argc, char **argv)
     bspgemm_stats stats;
     memset(&stats, 0, sizeof stats);
     int64_t *hrow = malloc(((size_t)(r1 - r0) + 1) * sizeof(int64_t));
+    (void)c_rows;
     for (int i = 0; i < times; i++) {
 #ifdef BSPGEMM_WITH_MPI
         MPI_Barrier(MPI_COMM_WORLD);                                     /* :319 */
 #endif
         const double t0 = now_s();                                       /* tic :320 */
         bspgemm_result *C;
-        CHECK(bspgemm_multiply(ctx, A, A, r0, r1, &C), "bspgemm_multiply");
+        CHECK(bspgemm_multiply(ctx, Lhs, A, r0, r1, &C), "bspgemm_multiply");
         long long local_nnz = bspgemm_result_nnz(C);
         nnzC = local_nnz;
 #ifdef BSPGEMM_WITH_MPI
@@ -131,6 +153,8 @@ int main(int argc, char **argv)
             CHECK(bspgemm_result_download(ctx, C, hrow, hcol), "download");
             const double e2e = now_s() - t0;
             if (e2e < e2e_fastest) e2e_fastest = e2e;
+            if (argc == 7 && i == times - 1 && numtasks == 1)            /* f2: C in the file's orientation */
+                CHECK(bspgemm_write_result_mtx(argv[6], c_rows, c_cols, hrow, hcol), "write C");
             free(hcol);                                                  /* isroot free(nCcol) :327 */
         }
         bspgemm_result_free(C);
@@ -158,6 +182,7 @@ int main(int argc, char **argv)
     free(alltimes); free(hrow); free(bounds);
     free(Acol); free(Arow);                                              /* :339-340 */
     bspgemm_matrix_free(A);
+    bspgemm_matrix_free(L);
 #ifdef BSPGEMM_WITH_MPI
     if (comm) bspgemm_comm_destroy(comm);
     free(shard_nnz);

@@ -99,6 +99,19 @@ bspgemm_status bspgemm_result_download(bspgemm_context *ctx, const bspgemm_resul
                                        int64_t *row_ptr, int *col_idx);
 void           bspgemm_result_free(bspgemm_result *C);
 
+/* A product becomes the next operand without leaving the GPU (int32 row_ptr copy; fails with
+ * BSPGEMM_ERR_OVERFLOW above 2^31-1 nonzeros).  `cols` = number of columns of C (= B.cols).      */
+bspgemm_status bspgemm_matrix_from_result(bspgemm_context *ctx, const bspgemm_result *C, int cols,
+                                          bspgemm_matrix **out);
+
+/* Reflexive-transitive closure by repeated boolean squaring, everything device-resident -- the
+ * application the reference's report motivates the kernel with (its old/BSpGEMM.c:75-126 keeps
+ * an OR-accumulating variant for it): T0 = A or I, T(k+1) = T(k)*T(k) until nnz stops growing
+ * (at most max_iter products; ceil(log2 n) suffice).  A must be square.  *iterations = products
+ * computed.  The result is T as a product object.                                              */
+bspgemm_status bspgemm_closure(bspgemm_context *ctx, const bspgemm_matrix *A, int max_iter,
+                               bspgemm_result **T, int *iterations);
+
 /* Per-row work F_i = sum_{j in A_i} |B_j| ("products", the flag probes of :36-38) as an
  * exclusive prefix over rows [0,A.rows]: prefix[rows] = F.  Used to cut GPU shards at equal
  * work instead of equal row counts (the reference cuts An/numtasks rows, :165). */

@@ -52,3 +52,46 @@ def test_mpi_driver_single_rank():
     r = _run([exe, MTX, "6250", "2", "3"])
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().split(",")[7] == "12502"
+
+
+def test_bench_driver_a_times_b_with_output(tmp_path):
+    """optional positionals: file-orientation A*B of rectangular files, C written"""
+    import numpy as np
+    import scipy.sparse as sp
+    import bspgemm
+    rng = np.random.default_rng(3)
+    A = sp.random(120, 80, density=0.05, random_state=rng, format="csr")
+    B = sp.random(80, 200, density=0.04, random_state=rng, format="csr")
+    for name, M in (("a.mtx", A), ("b.mtx", B)):
+        T = M.T.tocsr()                      # write_mtx takes the loader's (transposed) CSR
+        T.sort_indices()
+        bspgemm.write_mtx(str(tmp_path / name), T.indptr, T.indices, cols=M.shape[0])
+    out = str(tmp_path / "c.mtx")
+    r = _run([os.path.join(PKG, "SpGEMM_hip"), str(tmp_path / "a.mtx"), "1", "1", "2", str(tmp_path / "b.mtx"), out])
+    assert r.returncode == 0, r.stderr
+    Cref = ((A != 0).astype(np.int32) @ (B != 0).astype(np.int32)).tocsr()
+    assert int(r.stdout.strip().split(",")[7]) == Cref.nnz
+    rp, ci, m, n = bspgemm.readCOO(out)      # loader view = C^T as CSR
+    assert (m, n) == (120, 200)
+    CT = Cref.T.tocsr()
+    CT.sort_indices()
+    assert np.array_equal(rp, CT.indptr) and np.array_equal(ci, CT.indices)
+
+
+def test_closure_driver(tmp_path):
+    import numpy as np
+    import bspgemm
+    n = 500
+    rng = np.random.default_rng(8)
+    # a ring plus a few chords: the closure is the full matrix, reached in ~log2(n) squarings
+    rows = np.concatenate([np.arange(n), rng.integers(0, n, 20)])
+    cols = np.concatenate([(np.arange(n) + 1) % n, rng.integers(0, n, 20)])
+    import gen
+    rp, ci = gen._csr_from_pairs(rows, cols, n)
+    bspgemm.write_mtx(str(tmp_path / "g.mtx"), rp, ci)
+    r = _run([os.path.join(PKG, "SpGEMM_hip_closure"), str(tmp_path / "g.mtx"), str(tmp_path / "t.mtx")])
+    assert r.returncode == 0, r.stderr
+    f = r.stdout.strip().split(",")
+    assert int(f[1]) == n and int(f[4]) == n * n and 1 <= int(f[3]) <= 12
+    trp, tci, _, _ = bspgemm.readCOO(str(tmp_path / "t.mtx"))
+    assert trp[-1] == n * n and np.array_equal(tci[:n], np.arange(n))

@@ -314,6 +314,29 @@ def test_more_than_int32_output_nonzeros(ctx):
     assert e.value.status == 5          # BSPGEMM_ERR_OVERFLOW
 
 
+def test_device_resident_closure(ctx):
+    """bspgemm_closure: (A or I)^(2^k) to the fixpoint, products chained on the GPU"""
+    sp = pytest.importorskip("scipy.sparse")
+    n = 3000
+    rng = np.random.default_rng(901)
+    rows, cols = rng.integers(0, n, 3300), rng.integers(0, n, 3300)      # sparse digraph, long paths
+    rp, ci = gen._csr_from_pairs(rows, cols, n)
+    A = ctx.upload(rp, ci, n)
+    T, products = ctx.closure(A)
+    trp, tci = T.download()
+    G = sp.csr_matrix((np.ones(ci.size, np.int8), ci, rp), shape=(n, n))
+    from scipy.sparse.csgraph import floyd_warshall  # noqa: F401  (dense n=3000 is too big: use BFS reachability)
+    from scipy.sparse.csgraph import breadth_first_order
+    # reachability of a sample of sources by BFS == the closure's rows
+    for src in (0, 17, 1234, n - 1):
+        reach = np.sort(breadth_first_order(G, src, directed=True, return_predecessors=False))
+        assert np.array_equal(tci[trp[src]:trp[src + 1]], reach), src
+    assert 1 <= products <= 14
+    # T is idempotent and exact: T*T == T through the oracle
+    erp, eci = O.spgemm(trp.astype(np.int32), tci, trp.astype(np.int32), tci, n)
+    assert_same(trp, tci, erp, eci)
+
+
 def test_boolean_closure_is_idempotent(ctx):
     """(I + A)^k reaches a fixpoint T with T*T == T (the motivating use)"""
     n = 600

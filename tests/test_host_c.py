@@ -72,6 +72,16 @@ def test_write_then_read_roundtrip(tmp_path):
     assert np.array_equal(rp4, crow) and np.array_equal(ci4, ccol)
 
 
+def test_rectangular_write_read_roundtrip(tmp_path):
+    """a CSR with R rows and K columns is the file matrix K x R (transposing loader, utils.c:77)"""
+    rp, ci = gen.uniform_rect(37, 91, 4, seed=9)
+    p = str(tmp_path / "rect.mtx")
+    bspgemm.write_mtx(p, rp, ci, cols=91)
+    assert open(p).read().split("\n")[1].split()[:2] == ["91", "37"]
+    rp2, ci2, m, n = bspgemm.readCOO(p)
+    assert (m, n) == (91, 37) and np.array_equal(rp, rp2) and np.array_equal(ci, ci2)
+
+
 def test_csr_equal_is_spgemm_valid():
     rp, ci, n = gen.uniform(100, 4, seed=5)
     assert bspgemm.csr_equal(rp, ci, rp, ci)
