@@ -82,6 +82,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError("%s is not built: run `make -C binary-spgemm_amd` "
                                 "(or __graft_entry__.build())" % LIB_PATH)
+    try:   # a process that also uses torch must load torch's bundled HIP runtime first (one runtime only)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     VP, PVP = C.c_void_p, C.POINTER(C.c_void_p)
     L.bspgemm_status_string.restype = C.c_char_p

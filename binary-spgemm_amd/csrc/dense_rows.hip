@@ -189,15 +189,16 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // Compaction: every row was written at its upper-bound offset Fprefix[r]; now that the counts
 // are scanned into C.row_ptr the rows are copied to their final place.  Pure streaming copy
 // (4 B read + 4 B written per output nonzero), driven by the DESTINATION: a workgroup owns
-// 16384 consecutive output nonzeros (64 KiB of C.col_idx), finds the rows that cover them by a
+// 32768 consecutive output nonzeros (128 KiB of C.col_idx), finds the rows that cover them by a
 // binary search in C.row_ptr, keeps their (row_ptr, shift) pairs in LDS 256 rows at a time and
 // copies 16 B per lane whenever four outputs lie in one row -- stores are always 16-B aligned
 // and fully coalesced, loads are the same stream displaced by the row's shift.  Work per
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
-constexpr int kCompactChunk = 16384;     // output nonzeros per workgroup
+constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
@@ -235,24 +236,43 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
         __syncthreads();
         const long long b0 = rp[0] > o0 ? rp[0] : o0;          // outputs covered by this batch and chunk
         const long long b1 = rp[nb] < o1 ? rp[nb] : o1;
-        for (long long g = (b0 >> 2) + tid; (g << 2) < b1; g += 256) {
-            const long long o = g << 2;
-            const long long oo = o > b0 ? o : b0;
-            int lo = 0, hi = nb;                 // rp[lo] <= oo < rp[hi]
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (rp[mid] <= oo) lo = mid; else hi = mid;
+        // two 16-B groups per thread per step: independent row searches and loads in flight
+        for (long long g0 = (b0 >> 2) + tid; (g0 << 2) < b1; g0 += 512) {
+            long long o[2], src[2];
+            bool fast[2], live[2];
+            int lo_r[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const long long g = g0 + u * 256;
+                o[u] = g << 2;
+                live[u] = o[u] < b1;
+                const long long oo = !live[u] ? b0 : (o[u] > b0 ? o[u] : b0);
+                int lo = 0, hi = nb;             // rp[lo] <= oo < rp[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rp[mid] <= oo) lo = mid; else hi = mid;
+                }
+                lo_r[u] = lo;
+                fast[u] = live[u] && o[u] >= b0 && o[u] + 3 < b1 && o[u] + 3 < rp[lo + 1];
+                src[u] = o[u] + sh[lo];
             }
-            if (o >= b0 && o + 3 < b1 && o + 3 < rp[lo + 1]) {
-                const Int4U v = *reinterpret_cast<const Int4U *>(tmp + o + sh[lo]);   // source only dword aligned
-                *reinterpret_cast<int4 *>(col_idx + o) = make_int4(v.x, v.y, v.z, v.w);
-            } else {
-                int r = lo;
-                for (int e = 0; e < 4; e++) {
-                    const long long oe = o + e;
-                    if (oe < b0 || oe >= b1) continue;
-                    while (rp[r + 1] <= oe) r++;
-                    col_idx[oe] = tmp[oe + sh[r]];
+            Int4U v[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (fast[u]) v[u] = *reinterpret_cast<const Int4U *>(tmp + src[u]);     // source only dword aligned
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (fast[u]) {
+                    const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
+                } else if (live[u]) {
+                    int r = lo_r[u];
+                    for (int e = 0; e < 4; e++) {
+                        const long long oe = o[u] + e;
+                        if (oe < b0 || oe >= b1) continue;
+                        while (rp[r + 1] <= oe) r++;
+                        col_idx[oe] = tmp[oe + sh[r]];
+                    }
                 }
             }
         }

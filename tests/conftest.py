@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- first: torch bundles its own HIP runtime; loading it before libbspgemm.so
+#                              keeps ONE runtime in the process (whichever libamdhip64 is loaded first wins)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "binary-spgemm_amd")):
