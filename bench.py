@@ -220,7 +220,8 @@ def main():
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             prof = json.load(open(path))
-            key = ("bsp::k_wave_rows<%d, %d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
+            twp = 2 if -(-n // (32 ** levels)) <= 128 else 4       # top-bitmap words per lane (csrc/wave_rows.inc)
+            key = ("bsp::k_wave_rows<%d, %d, %d>" % (levels, BIN_CAPS[dom] // 64, twp)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
             if prof.get("workload") == wname and world == 1 and tiles == 1 and key in prof.get("kernels", {}):
                 k = prof["kernels"][key]
                 traffic = int(k["fetch_bytes"] + k["write_bytes"])
