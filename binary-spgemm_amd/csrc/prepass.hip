@@ -20,6 +20,8 @@
 
 namespace bsp {
 
+struct __attribute__((packed, aligned(4))) Int2U { int x, y; };   // 8 B, only dword aligned
+
 // ---------------------------------------------------------------------------------------
 // 8 lanes per A row: lanes stride the row's col_idx (coalesced 32-B pieces), gather the
 // B.row_ptr pair of every nonzero, reduce over the 8 lanes.
@@ -38,8 +40,9 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
         const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
         for (int jj = a0 + sub; jj < a1; jj += 8) {
             const int j = Acol[jj];
-            const int bs = Brow[j];
-            const int len = Brow[j + 1] - bs;
+            const Int2U pr = *reinterpret_cast<const Int2U *>(Brow + j);   // one 8-B gather (dword aligned)
+            const int bs = pr.x;
+            const int len = pr.y - bs;
             ab[jj] = make_int2(bs, len);
             sum += (long long)len;
         }
