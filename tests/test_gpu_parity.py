@@ -285,6 +285,65 @@ def test_rmat_scale20_properties_and_sampled_rows(ctx):
         assert np.array_equal(cci[crp[r0]:crp[r0 + 4096]], eci)
 
 
+def _sampled_rows_exact(rp, ci, n, crp, col_tensor, starts, block=64):
+    for r0 in starts:
+        erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0, r0 + block)
+        assert np.array_equal(crp[r0:r0 + block + 1] - crp[r0], erp), r0
+        got = col_tensor[int(crp[r0]): int(crp[r0 + block])].cpu().numpy()
+        assert np.array_equal(got, eci), r0
+
+
+def test_baseline_cfg4_rmat_scale24_shards(ctx):
+    """BASELINE config 4 shape: R-MAT scale 24 (n = 16.7 M, five-bit levels = 4, nnz(C) = 5.45 G > 2^32),
+    multiplied as 8 equal-work row shards like the 8-GPU run; every shard's rows sampled exactly,
+    shard sizes add up, int64 row_ptr throughout."""
+    import torch
+    from bspgemm import dist as bdist
+    dev = torch.device("cuda", 0)
+    rp, ci, n = bspgemm.gen_rmat(24, 16, (0.30, 0.25, 0.25), seed=1)
+    A = ctx.upload(rp, ci, n)
+    prefix = ctx.row_work_prefix(A, A)
+    bounds = bdist.shard_bounds(prefix, 8)
+    total_nnz, total_F = 0, 0
+    for p in range(8):
+        r0, r1 = int(bounds[p]), int(bounds[p + 1])
+        C = ctx.multiply(A, A, r0, r1)
+        st = ctx.stats()
+        crp, _ = C.download(col_idx=False)
+        assert crp[0] == 0 and crp[-1] == C.nnz and np.all(np.diff(crp) >= 0)
+        cols = bdist.device_tensor(C.col_idx_device, C.nnz, torch.int32, dev)
+        for s0 in (0, (r1 - r0) // 2, r1 - r0 - 32):
+            erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0 + s0, r0 + s0 + 32)
+            assert np.array_equal(crp[s0:s0 + 33] - crp[s0], erp)
+            assert np.array_equal(cols[int(crp[s0]): int(crp[s0 + 32])].cpu().numpy(), eci)
+        total_nnz += C.nnz
+        total_F += st["products"]
+        C.free()
+    assert total_F == int(prefix[-1]) and total_nnz > 2**32
+    work = np.diff(prefix[bounds])
+    assert work.max() < 1.05 * work.mean()
+
+
+def test_baseline_cfg5_powerlaw_full_size(ctx):
+    """BASELINE config 5 at full size: power-law n = 2^20, mean degree 64 -- all capacity classes and
+    ~170 K dense-window rows; well-formed, product count exact, hub and tail rows sampled exactly."""
+    import torch
+    from bspgemm import dist as bdist
+    rp, ci, n = bspgemm.gen_powerlaw(1 << 20, 64, seed=1)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A)
+    st = ctx.stats()
+    crp, _ = C.download(col_idx=False)
+    assert crp[-1] == C.nnz and np.all(np.diff(crp) >= 0)
+    assert st["products"] == O.count_products(rp, ci, rp) and st["rows_per_bin"][-1] > 1000
+    cols = bdist.device_tensor(C.col_idx_device, C.nnz, torch.int32, torch.device("cuda", 0))
+    deg = np.diff(rp)
+    hub = int(np.argmax(deg))
+    starts = [0, max(hub - 8, 0), n // 3, n - 64]
+    _sampled_rows_exact(rp, ci, n, crp, cols, starts, block=16)
+    C.free()
+
+
 def test_more_than_int32_output_nonzeros(ctx):
     """nnz(C) > 2^31-1 (what BASELINE configs 4 and 5 need and the reference's `int` counters cannot
     hold, final/SpGEMM_mpi_omp.c:20,111,177): int64 row_ptr end to end, sampled rows exact, and the
