@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 RMAT_MILD = (0.30, 0.25, 0.25)  # d = 0.20
-BIN_CAPS = [0, 64, 128, 256, 512, 1024, 2048]          # csrc/kernels.hpp: one-wave capacity classes
+BIN_CAPS = [0, 64, 128, 256, 512, 768, 1024, 2048]     # csrc/kernels.hpp: one-wave capacity classes
 DENSE_BIN = len(BIN_CAPS)                               # class of the dense-window rows
 
 
@@ -70,9 +70,9 @@ def bin_of(F):
     """capacity class of a row with F products -- same rule as csrc/prepass.hip bin_of()"""
     b = np.zeros(F.shape, dtype=np.int64)
     b[F > 0] = 1
-    for k in range(1, 6):
-        b[F > (64 << (k - 1))] = k + 1
-    b[F > 2048] = 7
+    for k in range(1, len(BIN_CAPS) - 1):
+        b[F > BIN_CAPS[k]] = k + 1
+    b[F > BIN_CAPS[-1]] = DENSE_BIN
     return b
 
 
@@ -169,7 +169,7 @@ def main():
 
     for _ in range(args.warmup):
         step().free()
-    bin_ms = np.zeros(8)
+    bin_ms = np.zeros(12)
     phase_ms = np.zeros(4)
     fence()
     t_start = time.perf_counter()
@@ -211,7 +211,7 @@ def main():
     bytes_dom //= tiles
     achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
-    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom <= 6 else "k_dense_rows"
+    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom < DENSE_BIN else "k_dense_rows"
     # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process,
     # so the committed rocprofv3 --pmc result of this very command is quoted when the workload is
     # the profiled one (tools/pmc_run.sh -> profiles/*_pmc_traffic.json); otherwise null.

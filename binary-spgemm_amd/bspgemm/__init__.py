@@ -56,9 +56,9 @@ class BspgemmError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz_a", C.c_int64), ("products", C.c_int64), ("nnz_c", C.c_int64),
-                ("bytes_alg", C.c_int64), ("rows_per_bin", C.c_int64 * 8), ("ms_total", C.c_float),
+                ("bytes_alg", C.c_int64), ("rows_per_bin", C.c_int64 * 12), ("ms_total", C.c_float),
                 ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_stitch", C.c_float),
-                ("ms_bin", C.c_float * 8), ("tiles", C.c_int)]
+                ("ms_bin", C.c_float * 12), ("tiles", C.c_int)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rows_per_bin", "ms_bin")}

@@ -97,7 +97,6 @@ struct bspgemm_context {
     int *tmp = nullptr;
     HostScalars *h = nullptr;          // pinned
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_bin[kNumBins + 1] = {};   // brackets of the per-class numeric launches
     // freed result buffers, reused by the next multiply (results are allocated per call like the
     // reference's per-call malloc of Ccol, final/SpGEMM_mpi_omp.c:115, without paying hipMalloc)
     struct CachedBuf { void *p; size_t bytes; };
@@ -153,7 +152,6 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
     for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
-    for (auto &e : ctx->ev_bin) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -173,7 +171,6 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab);
     if (ctx->h) hipHostFree(ctx->h);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
-    for (auto &e : ctx->ev_bin) if (e) hipEventDestroy(e);
     for (auto &c : ctx->cache) if (c.p) hipFree(c.p);
     if (ctx->stream_b) { hipStreamSynchronize(ctx->stream_b); hipStreamDestroy(ctx->stream_b); }
     if (ctx->stream_c) { hipStreamSynchronize(ctx->stream_c); hipStreamDestroy(ctx->stream_c); }
@@ -454,7 +451,7 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
             cls_n[k][b] = n;
             if (n <= 0) continue;
             // the two heaviest classes go to different streams so that every tile keeps the chip full
-            hipStream_t sx = (T > 1 && (b == 3 || b == 5 || b == 6)) ? sB : s;
+            hipStream_t sx = (T > 1 && (b & 1)) ? sB : s;
             const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
             const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
             HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));

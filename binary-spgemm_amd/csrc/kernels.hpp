@@ -6,10 +6,19 @@
 
 namespace bsp {
 
-// one-wave-per-row capacity classes: bin b (1..6) holds rows with F_i <= 64 << (b-1)
-constexpr int kNumBins = 8;             // 0 empty, 1..6 wave rows, 7 dense-window rows
-constexpr int kWaveBins = 6;
-constexpr int kMaxWaveCap = 64 << (kWaveBins - 1);   // 2048 products
+// capacity classes of a row by its product count F_i:
+//   0          : empty
+//   1..7       : one wavefront per row, capacity 64*kWaveChunks[b] products
+//                (64,128,256,512,768,1024,2048: the 768 class exists because LDS per wave, and with
+//                it the number of resident waves, follows the capacity -- most rows between 512 and
+//                1024 products are below 768)
+//   kDenseBin  : dense-window rows (F_i > 2048)
+constexpr int kWaveBins = 7;
+constexpr int kNumBins = kWaveBins + 2;
+constexpr int kDenseBin = kNumBins - 1;
+constexpr int kMaxBins = 12;            // size of the per-class arrays in bspgemm_stats
+constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 4, 8, 12, 16, 32};
+constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
 constexpr int kRowsPerWave = 16;         // consecutive list entries handled by one wave
 
 constexpr int kWaveTopWords = 256;      // 32-bit words of the directly addressed top bitmap

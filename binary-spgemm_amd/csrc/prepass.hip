@@ -69,14 +69,16 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;   // 2048 values per workgroup
 
-// capacity class of a row with F products: 0 empty, 1..6 one wave (64<<(b-1)), 7 dense window
+// capacity class of a row with F products (see kernels.hpp)
 __device__ __forceinline__ int bin_of(long long F)
 {
     if (F <= 0) return 0;
-    if (F > kMaxWaveCap) return 7;
+    if (F > kMaxWaveCap) return kDenseBin;
     const int f = (int)F;
-    const int hb = 32 - __clz(f - 1);          // bits needed for f-1 (0 for f == 1)
-    return hb <= 6 ? 1 : hb - 5;
+    int b = 1;
+#pragma unroll
+    for (int k = 1; k < kWaveBins; k++) b += (f > 64 * kWaveChunks[k]) ? 1 : 0;
+    return b;
 }
 
 template <typename T, bool BIN>

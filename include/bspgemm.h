@@ -130,12 +130,13 @@ typedef struct bspgemm_stats {
     int64_t products;        /* F                                                            */
     int64_t nnz_c;           /* output nonzeros                                              */
     int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
-    int64_t rows_per_bin[8]; /* [0] empty, [1..6] one-wave rows by capacity, [7] dense-window */
+    int64_t rows_per_bin[12];/* [0] empty, [1..7] one-wave rows by capacity (64,128,256,512,768,1024,
+                                2048 products), [8] dense-window, rest unused                */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* row work + scan + binning                                    */
     float   ms_numeric;      /* accumulate + emit kernels (the dominant kernels)             */
     float   ms_stitch;       /* count scan + compaction into the final col_idx               */
-    float   ms_bin[8];       /* per capacity class: summed duration of that class's launches */
+    float   ms_bin[12];      /* per capacity class: summed duration of that class's launches */
     int     tiles;           /* row super-tiles (each class is launched once per tile)       */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
