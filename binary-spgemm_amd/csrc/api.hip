@@ -70,6 +70,7 @@ struct HostScalars {
     long long nnzC;
     int bin_count[kNumBins];
     int a_lo, a_hi;
+    long long products;                 // true product count of a masked multiply (totalF is the mask total there)
     long long fb[kMaxTiles + 1];        // Fprefix at the super-tile boundaries
 };
 
@@ -86,7 +87,7 @@ struct bspgemm_context {
     size_t h_bin_tiles_cap = 0;
     // per-row workspace (capacity rows_cap rows)
     size_t rows_cap = 0;
-    long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr;
+    long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr, *Fmask = nullptr;
     int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
     RowRec *rec = nullptr;
     // per-A-nonzero workspace: (start,length) of the B row behind every A nonzero
@@ -168,7 +169,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
-    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab);
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask);
     if (ctx->h) hipHostFree(ctx->h);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &c : ctx->cache) if (c.p) hipFree(c.p);
@@ -264,14 +265,15 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     if (rows <= ctx->rows_cap) return BSPGEMM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_tiles);
-    hipFree(ctx->rec); hipFree(ctx->recpre);
-    ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = nullptr;
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask);
+    ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = ctx->Fmask = nullptr;
     ctx->cnt = ctx->bin_tiles = nullptr;
     ctx->rec = nullptr;
     ctx->rows_cap = 0;
     const size_t cap = rows + rows / 8 + 64;
     const size_t tiles = cap / 2048 + 2;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->F), cap * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fmask), cap * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fprefix), (cap + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->partials), (tiles + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->cnt), cap * sizeof(int)));
@@ -415,9 +417,18 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
 
     // ---- symbolic: per-row products, their prefix, capacity classes ---------------------
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
-    launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, s);
     HostScalars *h = ctx->h;
+    h->products = -1;
+    const long long *size_by = ctx->F;          // what rows are binned and offset by: products ...
+    if (Fm) {                                   // ... or, masked, the mask row's length (|C_i| <= |F_i|)
+        launch_sum_i64(ctx->F, R, ctx->partials, s);
+        HIPCHK_C(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
+                                hipMemcpyDeviceToHost, s));
+        launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
+        size_by = ctx->Fmask;
+    }
+    launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, s);
     HIPCHK_C(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_C(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -455,7 +466,10 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
             const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
             const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
             HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));
-            if (Fm)
+            if (Fm && b <= kWaveBins && wave_masked_supported(B->cols))
+                launch_wave_masked(b, ctx->ab, B->d_col_idx, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
+                                   row_begin, ctx->tmp, ctx->cnt, sx);
+            else if (Fm)
                 HIPCHK_C(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
                                                   ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
             else if (b <= kWaveBins)
@@ -492,9 +506,9 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
     memset(&st, 0, sizeof st);
     st.rows = R;
     st.nnz_a = R > 0 ? (long long)h->a_hi - h->a_lo : 0;
-    st.products = totalF;
+    st.products = (Fm && R > 0) ? h->products : totalF;
     st.nnz_c = C->nnz;
-    st.bytes_alg = 4ll * (R + 1) + 12ll * st.nnz_a + 4ll * totalF + 4ll * C->nnz + 8ll * (R + 1);
+    st.bytes_alg = 4ll * (R + 1) + 12ll * st.nnz_a + 4ll * st.products + 4ll * C->nnz + 8ll * (R + 1);
     for (int b = 0; b < kNumBins; b++) st.rows_per_bin[b] = h->bin_count[b];
     hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[3]);
     hipEventElapsedTime(&st.ms_symbolic, ctx->ev[0], ctx->ev[1]);

@@ -74,6 +74,16 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
                                     const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                                     int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s);
 
+// mask-first one-wave path of the masked product (mask rows <= 2048 entries, cols <= 2^23)
+bool wave_masked_supported(int cols);
+void launch_wave_masked(int bin, const int2 *ab, const int *Bcol, int cols, const int *Frow, const int *Fcol,
+                        const RowRec *rec, const long long *recpre, int nrows, int row_begin,
+                        int *tmp, int *cnt, hipStream_t s);
+// mlen[i] = |F's row i| when row i has products, else 0: what the masked product bins and offsets by
+void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int n, long long *mlen, hipStream_t s);
+// partials[ceil(n/2048)] = sum of F[0..n)
+void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s);
+
 // rows [row_lo,row_hi): tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..).  The output range
 // is read from row_ptr on the device; `max_out` (an upper bound of its length, e.g. the rows'
 // product count) only sizes the grid.

@@ -233,6 +233,14 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
                        prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr);
 }
 
+void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s)
+{
+    if (n <= 0) { hipMemsetAsync(partials, 0, sizeof(long long), s); return; }
+    const int tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr);
+}
+
 // prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
 // prefix[0]: a range of rows continues the row_ptr of the rows before it
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,

@@ -76,4 +76,41 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Blocked scan of a slot array of 64*W words: lane l owns the W consecutive words [l*W, l*W+W)
+// (vector LDS reads), does its own running popcount in registers, ONE wave scan joins the lanes,
+// and the W prefixes go back as one vector store.  pre[t] = number of set bits in P[0..t).
+// Cost is fixed per row (the arrays are zero beyond the live slots) and replaces a loop of
+// ceil(n/64) dependent scan steps.
+template <int W>
+__device__ __forceinline__ int scan_blocked(const u32 *P, unsigned short *pre, int lane)
+{
+    u32 x[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) x[k] = P[lane * W + k];
+    int e[W];
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        e[k] = run;
+        run += __popc(x[k]);
+    }
+    const int inc = wave_incl_scan(run);
+    const int base = inc - run;
+#pragma unroll
+    for (int k = 0; k < W; k++) pre[lane * W + k] = (unsigned short)(base + e[k]);
+    return wave_bcast(inc, 63);
+}
+
+// Staging index swizzle: lanes write runs of ~W consecutive outputs, i.e. at a stride of ~W words
+// (8-way bank conflicts at stride 8); XOR-ing the low 5 bits with the next 5 spreads any such
+// stride over all 32 banks and keeps the final contiguous read-out conflict-free.
+__device__ __forceinline__ int stage_swz(int x) { return x ^ ((x >> 5) & 31); }
+
+template <int W>
+__device__ __forceinline__ void clear_blocked(u32 *P, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < W; k++) P[lane * W + k] = 0u;
+}
+
 }  // namespace bsp

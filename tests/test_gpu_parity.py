@@ -202,7 +202,7 @@ def test_masked_golden_and_dropin(ctx):
     assert_same(crow, ccol, g["c_rp"], g["c_ci"])
 
 
-@pytest.mark.parametrize("ncols", [5000, 700_000], ids=["one_window", "two_windows"])
+@pytest.mark.parametrize("ncols", [5000, 100_000, 700_000], ids=["levels1", "levels2", "levels3_two_windows"])
 def test_masked_against_oracle(ctx, ncols):
     """rectangular A != B, mask rows of mixed length (empty, short, dense), row sub-range"""
     a_rp, a_ci = gen.uniform_rect(900, 700, 9, seed=801)
@@ -222,6 +222,19 @@ def test_masked_against_oracle(ctx, ncols):
     C2 = ctx.multiply_masked(A, B, F, 100, 433)                 # interior rows keep F aligned by row id
     r2, c2 = C2.download()
     assert np.array_equal(r2, erp[100:434] - erp[100]) and np.array_equal(c2, eci[erp[100]:erp[433]])
+
+
+def test_masked_triangle_pattern(ctx):
+    """C = A .* (A*A) on a skewed graph (the triangle-counting use of the masked product): mask rows
+    of every capacity class, product counts far above the mask lengths (products are streamed)"""
+    rp, ci, n = gen.rmat(14, 16, (0.57, 0.19, 0.19, 0.05), 811)
+    erp, eci = O.spgemm_masked(rp, ci, rp, ci, n, rp, ci)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply_masked(A, A, A)
+    crp, cci = C.download()
+    assert_same(crp, cci, erp, eci)
+    st = ctx.stats()
+    assert st["products"] == O.count_products(rp, ci, rp) and st["nnz_c"] == erp[-1]
 
 
 # ---------------------------------------------------------------- (3) properties at size --
