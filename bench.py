@@ -131,6 +131,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
 
+    # torch.distributed.run exports OMP_NUM_THREADS=1 for every rank; the host-side generators
+    # (OpenMP, csr_gen.c) would then build the scale-25 matrix on one core.  Give each rank its share.
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 16) // world)))
+
     import torch
     import torch.distributed as dist
     import bspgemm
