@@ -125,6 +125,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: RCCL prints a version banner there when the first
+    # communicator is created.  Everything else is sent to stderr for the whole run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,8 +151,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or os.environ.get("BSPGEMM_BENCH_FORCE_DIST") == "1"   # 1-rank rehearsal of the N>1 path
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t0 = time.perf_counter()
     rp, ci, n, wname = make_matrix(args, world)
@@ -161,14 +171,14 @@ def main():
 
     def step():
         C = ctx.multiply(A, A, r0, r1)
-        if world > 1:
+        if use_dist:
             local_rp = bdist.device_tensor(C.row_ptr_device, C.rows + 1, torch.int64, dev)
             bdist.stitch_row_ptr(local_rp, bounds)
         return C
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,7 +198,7 @@ def main():
         phase_ms += np.array([st["ms_total"], st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"]])
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -265,8 +275,9 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
             out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
