@@ -196,6 +196,7 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
 constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
+constexpr int kCompactSparseRows = 4096; // a chunk spanning more rows than this is searched per output
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
 {
     __shared__ long long rp[kCompactBatch + 1];
     __shared__ long long sh[kCompactBatch];      // source offset - destination offset of the row
-    __shared__ int r_first;
+    __shared__ int r_first, r_last;
     const int tid = threadIdx.x;
     const long long out_lo = row_ptr[row_lo], out_hi = row_ptr[row_hi];
     // chunk starts are multiples of 4 outputs so that the 16-B stores stay aligned
@@ -224,8 +225,29 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
             if (row_ptr[mid] <= o0) lo = mid; else hi = mid;
         }
         r_first = lo;
+        // ... and the row that holds the chunk's last output
+        lo = r_first, hi = row_hi;               // invariant: row_ptr[lo] <= o1 - 1 < row_ptr[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (row_ptr[mid] <= o1 - 1) lo = mid; else hi = mid;
+        }
+        r_last = lo;
     }
     __syncthreads();
+    if (r_last - r_first > kCompactSparseRows) {
+        // Mostly empty rows (a masked product, a very sparse result): staging every row of the span
+        // through LDS would walk millions of empty rows in ONE workgroup.  Search per output instead.
+        const int rf = r_first, rl = r_last;
+        for (long long o = o0 + tid; o < o1; o += 256) {
+            int lo = rf, hi = rl + 1;            // row_ptr[lo] <= o < row_ptr[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (row_ptr[mid] <= o) lo = mid; else hi = mid;
+            }
+            col_idx[o] = tmp[Fprefix[lo] + (o - row_ptr[lo])];
+        }
+        return;
+    }
     int rbase = r_first;
     while (true) {
         const int nb = (row_hi - rbase < kCompactBatch) ? row_hi - rbase : kCompactBatch;   // rows staged

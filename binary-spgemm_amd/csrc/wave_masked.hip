@@ -20,14 +20,15 @@
 namespace bsp {
 
 constexpr int kMaskWinChunks = 4;       // products per window = 256, kept in registers
+constexpr long long kMaskWaveMaxProducts = 8192;   // beyond this a row is streamed by a whole workgroup
 
 template <int LEVELS, int CHUNKS>
 struct MaskCfg {
     static constexpr int CAP = 64 * CHUNKS;
     static constexpr int TOPW = 256;
     static constexpr int bytes_per_wave = 4 * TOPW + 2 * TOPW + 8 * kMaskWinChunks + 4 * 64      // top, topPre, starts, delta
-                                          + 4 * (CAP + 4) * 3                                    // SA, K0, L0w
-                                          + (LEVELS >= 3 ? 4 * (CAP + 4) + 2 * CAP : 32)         // SB, preB
+                                          + 4 * CAP * 3                                          // SA, K0, L0w
+                                          + (LEVELS >= 3 ? 4 * CAP + 2 * CAP : 32)               // SB, preB
                                           + 0;
     static constexpr int w4 = (4 * bytes_per_wave > 64 * 1024) ? 0 : (160 * 1024 / (4 * bytes_per_wave)) * 4;
     static constexpr int w2 = (2 * bytes_per_wave > 64 * 1024) ? 0 : (160 * 1024 / (2 * bytes_per_wave)) * 2;
@@ -48,11 +49,11 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
     __shared__ __attribute__((aligned(16))) unsigned short s_topPre[WAVES][TOPW];
     __shared__ __attribute__((aligned(16))) u64 s_starts[WAVES][PCH];
     __shared__ __attribute__((aligned(16))) int s_delta[WAVES][64];
-    __shared__ __attribute__((aligned(16))) u32 s_SA[WAVES][CAP + 4];       // level-0 masks of the MASK row
+    __shared__ __attribute__((aligned(16))) u32 s_SA[WAVES][CAP];           // level-0 masks of the MASK row
     constexpr int KN = (LEVELS == 1) ? TOPW : CAP;                 // level-0 slots: the top words themselves when LEVELS == 1
-    __shared__ __attribute__((aligned(16))) u32 s_K0[WAVES][KN + 4];        // kept bits (index KN = trash)
-    __shared__ __attribute__((aligned(16))) u32 s_L0w[WAVES][CAP + 4];      // word id of every level-0 slot; emit staging
-    __shared__ __attribute__((aligned(16))) u32 s_SB[WAVES][LEVELS >= 3 ? CAP + 4 : 4];
+    __shared__ __attribute__((aligned(16))) u32 s_K0[WAVES][KN];            // kept bits
+    __shared__ __attribute__((aligned(16))) u32 s_L0w[WAVES][CAP];          // word id of every level-0 slot; emit staging
+    __shared__ __attribute__((aligned(16))) u32 s_SB[WAVES][LEVELS >= 3 ? CAP : 4];
     __shared__ __attribute__((aligned(16))) unsigned short s_preB[WAVES][LEVELS >= 3 ? CAP : 8];
 
     const int lane = lane_id();
@@ -83,8 +84,7 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
     if (lane < PCH) starts[lane] = 0ull;
     clear_blocked<CHUNKS>(SA, lane);
     clear_blocked<KN / 64>(K0, lane);
-    if (lane < 4) { SA[CAP + lane] = 0u; K0[KN + lane] = 0u; }
-    if (LEVELS >= 3) { clear_blocked<CHUNKS>(SB, lane); if (lane < 4) SB[CAP + lane] = 0u; }
+    if (LEVELS >= 3) clear_blocked<CHUNKS>(SB, lane);
     wave_lds_fence();
 
     for (int kk = 0; kk < nmine; kk++) {
@@ -109,7 +109,7 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
             const u32 cc = ok ? (u32)mcol[c] : 0u;
             mcol[c] = (int)cc;
             const u32 tw = cc >> (5 * LEVELS);
-            atomicOr(&top[tw], ok ? (1u << ((cc >> (5 * (LEVELS - 1))) & 31)) : 0u);
+            if (ok) atomicOr(&top[tw], 1u << ((cc >> (5 * (LEVELS - 1))) & 31));   // tail lanes masked off
             rank[c] = (int)tw;
         }
         wave_lds_fence();
@@ -131,9 +131,10 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
                     const int pre = Ppre[rank[c]];
                     const u32 b = (cc >> (5 * (lev + 1))) & 31;
                     const int r2 = pre + __popc(x & ((1u << b) - 1u));
-                    const int slot = ok ? r2 : CAP;
-                    atomicOr(&S[slot], 1u << ((cc >> (5 * lev)) & 31));
-                    if (lev == 0) L0w[slot] = cc >> 5;
+                    if (ok) {
+                        atomicOr(&S[r2], 1u << ((cc >> (5 * lev)) & 31));
+                        if (lev == 0) L0w[r2] = cc >> 5;
+                    }
                     rank[c] = r2;
                 }
                 wave_lds_fence();
@@ -213,7 +214,9 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
                     }
                     const u32 b0 = cc & 31;
                     hit = hit && ((x >> b0) & 1u);
-                    atomicOr(&K0[hit ? r : KN], 1u << b0);
+                    // only the hits touch K0: parking the misses (the vast majority of a sparse
+                    // masked product) on one spare word serialises them as same-address atomics
+                    if (hit) atomicOr(&K0[r], 1u << b0);
                 }
                 wave_lds_fence();
             }
@@ -308,7 +311,14 @@ __global__ void k_mask_lengths(const long long *__restrict__ F, const int *__res
                                int n, long long *__restrict__ mlen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mlen[i] = F[i] > 0 ? (long long)(Frow[row_begin + i + 1] - Frow[row_begin + i]) : 0;
+    if (i < n) {
+        long long m = F[i] > 0 ? (long long)(Frow[row_begin + i + 1] - Frow[row_begin + i]) : 0;
+        // a wave streams its row's products 256 at a time: rows with very many products go to the
+        // 1024-thread dense kernel whatever their mask length (class = dense when m > kMaxWaveCap;
+        // the larger m only reserves more room in tmp)
+        if (m > 0 && m <= kMaxWaveCap && F[i] > kMaskWaveMaxProducts) m = kMaxWaveCap + 1;
+        mlen[i] = m;
+    }
 }
 
 void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int n, long long *mlen, hipStream_t s)
