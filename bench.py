@@ -34,8 +34,6 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 RMAT_MILD = (0.30, 0.25, 0.25)  # d = 0.20
-BIN_CAPS = [0, 64, 128, 256, 512, 768, 1024, 2048]     # csrc/kernels.hpp: one-wave capacity classes
-DENSE_BIN = len(BIN_CAPS)                               # class of the dense-window rows
 
 
 def log(rank, *a):
@@ -66,13 +64,13 @@ def make_matrix(args, world):
     return rp, ci, n, name
 
 
-def bin_of(F):
-    """capacity class of a row with F products -- same rule as csrc/prepass.hip bin_of()"""
+def bin_of(F, caps):
+    """capacity class of a row with F products -- same rule as csrc/prepass.hip bin_of(); `caps` is
+    bspgemm_stats.bin_cap: caps[0] = 0 (empty rows), caps[-1] = INT32_MAX (heavy rows)"""
     b = np.zeros(F.shape, dtype=np.int64)
     b[F > 0] = 1
-    for k in range(1, len(BIN_CAPS) - 1):
-        b[F > BIN_CAPS[k]] = k + 1
-    b[F > BIN_CAPS[-1]] = DENSE_BIN
+    for k in range(1, len(caps) - 1):
+        b[F > caps[k]] = k + 1
     return b
 
 
@@ -184,7 +182,7 @@ def main():
 
     for _ in range(args.warmup):
         step().free()
-    bin_ms = np.zeros(12)
+    bin_ms = None
     phase_ms = np.zeros(4)
     fence()
     t_start = time.perf_counter()
@@ -194,7 +192,7 @@ def main():
             last.free()
         last = step()
         st = ctx.stats()
-        bin_ms += np.array(st["ms_bin"])
+        bin_ms = np.array(st["ms_bin"]) if bin_ms is None else bin_ms + np.array(st["ms_bin"])
         phase_ms += np.array([st["ms_total"], st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"]])
     fence()
     elapsed = time.perf_counter() - t_start
@@ -217,7 +215,9 @@ def main():
     F_row = np.diff(prefix)[r0:r1]
     a_row = np.diff(rp.astype(np.int64))[r0:r1]
     c_row = np.diff(crp)
-    bins = bin_of(F_row)
+    caps = st["bin_cap"]
+    DENSE_BIN = len(caps) - 1
+    bins = bin_of(F_row, caps)
     dom = int(np.argmax(bin_ms))
     sel = bins == dom
     bytes_dom = int(4 * F_row[sel].sum() + 4 * c_row[sel].sum() + 12 * a_row[sel].sum() + 12 * sel.sum())
@@ -226,7 +226,7 @@ def main():
     bytes_dom //= tiles
     achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
-    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, BIN_CAPS[dom] // 64)) if 1 <= dom < DENSE_BIN else "k_dense_rows"
+    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, caps[dom] // 64)) if 1 <= dom < DENSE_BIN else "k_dense_rows"
     # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process,
     # so the committed rocprofv3 --pmc result of this very command is quoted when the workload is
     # the profiled one (tools/pmc_run.sh -> profiles/*_pmc_traffic.json); otherwise null.
@@ -236,7 +236,7 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             prof = json.load(open(path))
             twp = 2 if -(-n // (32 ** levels)) <= 128 else 4       # top-bitmap words per lane (csrc/wave_rows.inc)
-            key = ("bsp::k_wave_rows<%d, %d, %d>" % (levels, BIN_CAPS[dom] // 64, twp)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
+            key = ("bsp::k_wave_rows<%d, %d, %d>" % (levels, caps[dom] // 64, twp)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
             if prof.get("workload") == wname and world == 1 and tiles == 1 and key in prof.get("kernels", {}):
                 k = prof["kernels"][key]
                 traffic = int(k["fetch_bytes"] + k["write_bytes"])
@@ -244,9 +244,15 @@ def main():
                 break
     except Exception:
         traffic = None
+    wave = (bins >= 1) & (bins < DENSE_BIN)             # all capacity classes of the one-wave kernel together
+    bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
+    ms_wave = float(bin_ms[1:DENSE_BIN].sum())
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": kernel,
+                "all_wave_classes": {"bytes": bytes_wave, "ms": round(ms_wave, 4),
+                                     "GBps": round(bytes_wave / (ms_wave * 1e-3) / 1e9, 1) if ms_wave > 0 else 0.0,
+                                     "frac": round(bytes_wave / (ms_wave * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_wave > 0 else 0.0},
                 "bytes_per_launch": bytes_dom, "ms_per_launch": round(ms_dom, 4),
                 "launch_rows": int(sel.sum()), "launch_products": int(F_row[sel].sum())}
 
@@ -266,7 +272,8 @@ def main():
                       "rank0_ms": {"total": round(float(phase_ms[0]), 4), "symbolic": round(float(phase_ms[1]), 4),
                                    "numeric": round(float(phase_ms[2]), 4), "stitch": round(float(phase_ms[3]), 4)},
                       "rank0_ms_per_bin": [round(float(x), 4) for x in bin_ms],
-                      "rank0_rows_per_bin": [int(x) for x in st["rows_per_bin"]]},
+                      "rank0_rows_per_bin": [int(x) for x in st["rows_per_bin"]],
+                      "bin_cap": [int(x) for x in st["bin_cap"]]},
     }
     last.free()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -54,16 +54,21 @@ class BspgemmError(RuntimeError):
         super().__init__("%s: %s %s" % (where, STATUS.get(status, status), msg))
 
 
+MAX_BINS = 20      # BSPGEMM_MAX_BINS
+
+
 class Stats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz_a", C.c_int64), ("products", C.c_int64), ("nnz_c", C.c_int64),
-                ("bytes_alg", C.c_int64), ("rows_per_bin", C.c_int64 * 12), ("ms_total", C.c_float),
+                ("bytes_alg", C.c_int64), ("rows_per_bin", C.c_int64 * MAX_BINS), ("ms_total", C.c_float),
                 ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_stitch", C.c_float),
-                ("ms_bin", C.c_float * 12), ("tiles", C.c_int)]
+                ("ms_bin", C.c_float * MAX_BINS), ("tiles", C.c_int), ("bins", C.c_int),
+                ("bin_cap", C.c_int * MAX_BINS)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("rows_per_bin", "ms_bin")}
-        d["rows_per_bin"] = list(self.rows_per_bin)
-        d["ms_bin"] = list(self.ms_bin)
+        arrays = ("rows_per_bin", "ms_bin", "bin_cap")
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in arrays}
+        for k in arrays:
+            d[k] = list(getattr(self, k))[: self.bins]
         return d
 
 

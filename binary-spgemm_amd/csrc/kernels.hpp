@@ -8,18 +8,21 @@ namespace bsp {
 
 // capacity classes of a row by its product count F_i:
 //   0          : empty
-//   1..7       : one wavefront per row, capacity 64*kWaveChunks[b] products
-//                (64,128,256,512,768,1024,2048: the 768 class exists because LDS per wave, and with
-//                it the number of resident waves, follows the capacity -- most rows between 512 and
-//                1024 products are below 768)
+//   1..16      : one wavefront per row, capacity 64*kWaveChunks[b] products.  The kernel body is
+//                straight-line over its CHUNKS 64-product chunks (exact s_waitcnt counts, no
+//                branches), so a row costs what its CLASS costs: the classes step by one chunk up
+//                to 512 products, by two up to 1024, then by four/eight
 //   kDenseBin  : dense-window rows (F_i > 2048)
-constexpr int kWaveBins = 7;
+constexpr int kWaveBins = 16;
 constexpr int kNumBins = kWaveBins + 2;
 constexpr int kDenseBin = kNumBins - 1;
-constexpr int kMaxBins = 12;            // size of the per-class arrays in bspgemm_stats
-constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 4, 8, 12, 16, 32};
+constexpr int kMaxBins = 20;            // size of the per-class arrays in bspgemm_stats
+constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
 constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
-constexpr int kRowsPerWave = 16;         // consecutive list entries handled by one wave
+#ifndef BSP_RPW
+#define BSP_RPW 16
+#endif
+constexpr int kRowsPerWave = BSP_RPW;         // consecutive list entries handled by one wave
 
 constexpr int kWaveTopWords = 256;      // 32-bit words of the directly addressed top bitmap
 

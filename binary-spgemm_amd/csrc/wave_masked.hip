@@ -277,16 +277,18 @@ static void launch_mask_levels(int bin, const int2 *ab, const int *Bcol, int top
                                const int *Fcol, const RowRec *rec, const long long *recpre, int nrows,
                                int row_begin, int *tmp, int *cnt, hipStream_t s)
 {
-    switch (bin) {
-    case 1: launch_mask_one<LEVELS, kWaveChunks[1]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 2: launch_mask_one<LEVELS, kWaveChunks[2]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 3: launch_mask_one<LEVELS, kWaveChunks[3]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 4: launch_mask_one<LEVELS, kWaveChunks[4]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 5: launch_mask_one<LEVELS, kWaveChunks[5]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 6: launch_mask_one<LEVELS, kWaveChunks[6]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    case 7: launch_mask_one<LEVELS, kWaveChunks[7]>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s); break;
-    default: break;
-    }
+    // the mask-first kernel is instantiated for 7 mask-row capacities; a class uses the smallest
+    // one that holds its rows (mask rows are short: the fine classes of the plain product buy nothing)
+    const int chunks = kWaveChunks[bin];
+#define BSP_MASK(C) launch_mask_one<LEVELS, C>(ab, Bcol, topw, Frow, Fcol, rec, recpre, nrows, row_begin, tmp, cnt, s)
+    if (chunks <= 1) BSP_MASK(1);
+    else if (chunks <= 2) BSP_MASK(2);
+    else if (chunks <= 4) BSP_MASK(4);
+    else if (chunks <= 8) BSP_MASK(8);
+    else if (chunks <= 12) BSP_MASK(12);
+    else if (chunks <= 16) BSP_MASK(16);
+    else BSP_MASK(32);
+#undef BSP_MASK
 }
 
 bool wave_masked_supported(int cols) { return levels_for_cols(cols) <= 3; }

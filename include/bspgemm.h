@@ -124,20 +124,25 @@ bspgemm_status bspgemm_partition_rows(bspgemm_context *ctx,
                                       int parts, int *bounds);
 
 /* counters of the last bspgemm_multiply* on this context */
+#define BSPGEMM_MAX_BINS 20
 typedef struct bspgemm_stats {
     int64_t rows;            /* rows multiplied                                              */
     int64_t nnz_a;           /* A nonzeros in those rows                                     */
     int64_t products;        /* F                                                            */
     int64_t nnz_c;           /* output nonzeros                                              */
     int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
-    int64_t rows_per_bin[12];/* [0] empty, [1..7] one-wave rows by capacity (64,128,256,512,768,1024,
-                                2048 products), [8] dense-window, rest unused                */
+    int64_t rows_per_bin[BSPGEMM_MAX_BINS]; /* rows per capacity class: [0] empty rows,
+                                [1..bins-2] one-wavefront rows with at most bin_cap[b] products,
+                                [bins-1] heavy rows (one workgroup each); rest unused        */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* row work + scan + binning                                    */
     float   ms_numeric;      /* accumulate + emit kernels (the dominant kernels)             */
     float   ms_stitch;       /* count scan + compaction into the final col_idx               */
-    float   ms_bin[12];      /* per capacity class: summed duration of that class's launches */
+    float   ms_bin[BSPGEMM_MAX_BINS];       /* per class: summed duration of its launches    */
     int     tiles;           /* row super-tiles (each class is launched once per tile)       */
+    int     bins;            /* classes in use, including [0] and the heavy class            */
+    int     bin_cap[BSPGEMM_MAX_BINS];      /* products a row of class b may have (masked product:
+                                mask-row length); 0 for [0], INT32_MAX for the heavy class   */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
 

@@ -12,6 +12,6 @@ for scale, abc in ((20, (0.30, 0.25, 0.25)), (22, (0.30, 0.25, 0.25)), (18, (0.5
             C = fn(); nnz = C.nnz; C.free()
         dt = (time.perf_counter() - t) / 5
         st = ctx.stats()
-        print("scale %d %s %-9s %.2f ms  products %.3g  nnz %.3g  bins %s" % (scale, abc, name, dt * 1e3, st["products"], nnz, st["rows_per_bin"][:9]))
-        print("    ms: symbolic %.3f numeric %.3f stitch %.3f per-bin %s" % (st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"], [round(x, 3) for x in st["ms_bin"][:9]]))
+        print("scale %d %s %-9s %.2f ms  products %.3g  nnz %.3g  bins %s" % (scale, abc, name, dt * 1e3, st["products"], nnz, st["rows_per_bin"]))
+        print("    ms: symbolic %.3f numeric %.3f stitch %.3f per-bin %s" % (st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"], [round(x, 3) for x in st["ms_bin"]]))
     A.free()

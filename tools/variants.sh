@@ -8,6 +8,6 @@ for v in "$@" ""; do
   make -C binary-spgemm_amd XDEF="$v" -j16 > /dev/null 2>&1 || { echo "build failed: $v"; exit 1; }
   for rep in 1 2; do
   python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys; d=json.load(sys.stdin); print('[${v:-default}]', d['ms_per_step'], d['whole_job']['rank0_ms']['numeric'], d['whole_job']['rank0_ms_per_bin'][1:9])"
+import json,sys; d=json.load(sys.stdin); print('[${v:-default}]', d['ms_per_step'], d['whole_job']['rank0_ms']['numeric'], d['whole_job']['rank0_ms_per_bin'][1:])"
   done
 done
