@@ -209,8 +209,14 @@ def main():
     phase_ms /= args.steps
 
     # ---- roofline of the dominant kernel (this rank's launches) -------------------------
-    # algorithmic bytes of the rows one launch of that capacity class processes:
-    # 4 B/product + 4 B/output nonzero + 12 B/A-nonzero + 12 B/row (A.row_ptr read, C.row_ptr written)
+    # The dominant kernel is k_wave_rows (csrc/wave_rows.inc): ONE kernel source, launched as one
+    # template instance per capacity class (16 of them), back to back on two streams so that one
+    # instance's tail overlaps the next one's ramp-up.  Its "launch" is therefore the whole family:
+    # algorithmic bytes of all one-wave rows (4 B/product + 4 B/output nonzero +
+    # 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start to the
+    # last one's end on the multiply's stream (bspgemm_stats.ms_numeric, which also holds the few
+    # heavy rows of k_dense_rows and the count scan: conservative).  Per-instance event brackets are
+    # listed next to it; they overlap pairwise, so their sum exceeds the family's time.
     crp, _ = last.download(col_idx=False)
     F_row = np.diff(prefix)[r0:r1]
     a_row = np.diff(rp.astype(np.int64))[r0:r1]
@@ -218,43 +224,40 @@ def main():
     caps = st["bin_cap"]
     DENSE_BIN = len(caps) - 1
     bins = bin_of(F_row, caps)
-    dom = int(np.argmax(bin_ms))
-    sel = bins == dom
-    bytes_dom = int(4 * F_row[sel].sum() + 4 * c_row[sel].sum() + 12 * a_row[sel].sum() + 12 * sel.sum())
     tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
-    ms_dom = float(bin_ms[dom]) / tiles
-    bytes_dom //= tiles
-    achieved = bytes_dom / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
-    kernel = ("k_wave_rows<LEVELS=%d,CHUNKS=%d>" % (levels, caps[dom] // 64)) if 1 <= dom < DENSE_BIN else "k_dense_rows"
-    # HBM traffic of that kernel per launch: PMC counters cannot be read from inside the process,
-    # so the committed rocprofv3 --pmc result of this very command is quoted when the workload is
-    # the profiled one (tools/pmc_run.sh -> profiles/*_pmc_traffic.json); otherwise null.
+    wave = (bins >= 1) & (bins < DENSE_BIN)
+    bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
+    ms_wave = float(phase_ms[2])
+    achieved = bytes_wave / (ms_wave * 1e-3) / 1e9 if ms_wave > 0 else 0.0
+    instances = []
+    for b in range(1, DENSE_BIN):
+        selb = bins == b
+        if selb.any():
+            instances.append({"chunks": caps[b] // 64, "rows": int(selb.sum()), "products": int(F_row[selb].sum()),
+                              "ms": round(float(bin_ms[b]) / tiles, 4)})
+    # HBM traffic: PMC counters cannot be read from inside the process, so the committed
+    # rocprofv3 --pmc result of this very command is quoted when the workload is the profiled one
+    # (tools/pmc_run.sh -> profiles/*_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE summed over the
+    # family's instances); otherwise null.
     traffic, traffic_src = None, None
     try:
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
             prof = json.load(open(path))
-            twp = 2 if -(-n // (32 ** levels)) <= 128 else 4       # top-bitmap words per lane (csrc/wave_rows.inc)
-            key = ("bsp::k_wave_rows<%d, %d, %d>" % (levels, caps[dom] // 64, twp)) if 1 <= dom < DENSE_BIN else "bsp::k_dense_rows<false>"
-            if prof.get("workload") == wname and world == 1 and tiles == 1 and key in prof.get("kernels", {}):
-                k = prof["kernels"][key]
-                traffic = int(k["fetch_bytes"] + k["write_bytes"])
-                traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE, uncorrected)"
+            fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
+            if prof.get("workload") == wname and world == 1 and tiles == 1 and len(fam) == len(instances):
+                traffic = int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))
+                traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE of the %d instances, uncorrected)" % len(fam)
                 break
     except Exception:
         traffic = None
-    wave = (bins >= 1) & (bins < DENSE_BIN)             # all capacity classes of the one-wave kernel together
-    bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
-    ms_wave = float(bin_ms[1:DENSE_BIN].sum())
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": kernel,
-                "all_wave_classes": {"bytes": bytes_wave, "ms": round(ms_wave, 4),
-                                     "GBps": round(bytes_wave / (ms_wave * 1e-3) / 1e9, 1) if ms_wave > 0 else 0.0,
-                                     "frac": round(bytes_wave / (ms_wave * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_wave > 0 else 0.0},
-                "bytes_per_launch": bytes_dom, "ms_per_launch": round(ms_dom, 4),
-                "launch_rows": int(sel.sum()), "launch_products": int(F_row[sel].sum())}
+                "kernel": "k_wave_rows<LEVELS=%d,*> (%d capacity-class instances, two streams)" % (levels, len(instances)),
+                "bytes_per_launch": bytes_wave, "ms_per_launch": round(ms_wave, 4),
+                "launch_rows": int(wave.sum()), "launch_products": int(F_row[wave].sum()),
+                "instances": instances}
 
     ms_per_step = elapsed / args.steps * 1e3
     value = nnz_total * args.steps / elapsed / 1e9

@@ -38,13 +38,29 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
     long long sum = 0;
     if (r < nrows) {
         const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
-        for (int jj = a0 + sub; jj < a1; jj += 8) {
-            const int j = Acol[jj];
-            const Int2U pr = *reinterpret_cast<const Int2U *>(Brow + j);   // one 8-B gather (dword aligned)
-            const int bs = pr.x;
-            const int len = pr.y - bs;
-            ab[jj] = make_int2(bs, len);
-            sum += (long long)len;
+#ifndef BSP_RW_UNROLL
+#define BSP_RW_UNROLL 4
+#endif
+        // U nonzeros per lane and trip: their A.col_idx loads, then their B.row_ptr gathers, are
+        // issued together (independent misses in flight instead of one dependent chain per nonzero)
+        constexpr int U = BSP_RW_UNROLL;
+        for (int jj = a0 + sub; jj < a1; jj += 8 * U) {
+            int j[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            Int2U pr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                pr[u].x = pr[u].y = 0;
+                if (j[u] >= 0) pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);   // one 8-B gather (dword aligned)
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (j[u] >= 0) {
+                    const int len = pr[u].y - pr[u].x;
+                    ab[jj + 8 * u] = make_int2(pr[u].x, len);
+                    sum += (long long)len;
+                }
         }
     }
     sum += __shfl_xor(sum, 1, 64);
