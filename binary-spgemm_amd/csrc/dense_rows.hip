@@ -21,6 +21,8 @@ namespace bsp {
 constexpr int kDenseThreads = 1024;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
 constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
+constexpr int kDenseWordBits = 12;           // 64-column words with at least this many outputs are emitted by a whole wave
+constexpr int kLongSrc = 128;                // B rows at least this long are loaded segment-wise by whole waves
 
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
@@ -43,9 +45,11 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
     u64 *bm = MASKED ? bmP + wwords : bmP;                             // what is read out (K or P)
     u32 *bmK32 = reinterpret_cast<u32 *>(bm);
-    __shared__ int wtot[kDenseThreads / 64];
-    __shared__ int s_pref[kDenseBatch + 1];     // product offset of each source in the batch
+    __shared__ int wtot[kDenseThreads / 64], wtot_ls[kDenseThreads / 64], wtot_lc[kDenseThreads / 64];
+    __shared__ int s_pref[kDenseBatch + 1];     // (short) product offset of each source in the batch
     __shared__ int s_bs[kDenseBatch];           // B.row_ptr of each source
+    __shared__ int s_lbs[kDenseBatch], s_llen[kDenseBatch];   // compacted long sources: start, length
+    __shared__ int s_lseg[kDenseBatch + 1];     // ... and exclusive prefix of their 64-product segments
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < (MASKED ? 2 * wwords : wwords); t += kDenseThreads) bmP[t] = 0ull;
@@ -57,29 +61,78 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     int *out = tmp + recpre[blockIdx.x];
     const long long W = (long long)wwords * 64;
     const int nwin = (int)(((long long)cols + W - 1) / W);
-    const int wpt = (wwords + kDenseThreads - 1) / kDenseThreads;
     int total = 0;
 
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         for (int ja = a0; ja < a1; ja += kDenseBatch) {
-            // one source (A-nonzero) per thread: extents -> exclusive product offsets
+            // one source (A-nonzero) per thread.  LONG sources (>= kLongSrc products: in a heavy
+            // row of a skewed graph they carry nearly all the products) are cut into 64-product
+            // segments that whole waves load with no per-product search; the SHORT ones are
+            // flattened product by product.  Three block scans: short products, long segments,
+            // long sources (the latter compacts the long sources into their own list).
             int2 e = make_int2(0, 0);
             if (ja + tid < a1) e = ab[ja + tid];
-            const int sinc = wave_incl_scan(e.y);
-            if (lane == 63) wtot[wave] = sinc;
+            const bool is_long = e.y >= kLongSrc;
+            const int v_sp = is_long ? 0 : e.y, v_ls = is_long ? (e.y + 63) >> 6 : 0, v_lc = is_long ? 1 : 0;
+            const int i_sp = wave_incl_scan(v_sp), i_ls = wave_incl_scan(v_ls), i_lc = wave_incl_scan(v_lc);
+            if (lane == 63) { wtot[wave] = i_sp; wtot_ls[wave] = i_ls; wtot_lc[wave] = i_lc; }
             __syncthreads();
-            int soff = sinc - e.y, pb = 0;
+            int soff = i_sp - v_sp, pb = 0, o_ls = i_ls - v_ls, SL = 0, o_lc = i_lc - v_lc, NL = 0;
             for (int k = 0; k < kDenseThreads / 64; k++) {
-                const int t = wtot[k];
-                if (k < wave) soff += t;
-                pb += t;
+                const int t = wtot[k], t2 = wtot_ls[k], t3 = wtot_lc[k];
+                if (k < wave) { soff += t; o_ls += t2; o_lc += t3; }
+                pb += t; SL += t2; NL += t3;
             }
             s_pref[tid] = soff;
             s_bs[tid] = e.x;
-            if (tid == 0) s_pref[kDenseBatch] = pb;
+            if (is_long) { s_lbs[o_lc] = e.x; s_llen[o_lc] = e.y; s_lseg[o_lc] = o_ls; }
+            if (tid == 0) { s_pref[kDenseBatch] = pb; s_lseg[NL] = SL; }
             __syncthreads();
-            // products of the batch, evenly over the threads, 4 independent gathers in flight
+            // long sources: wave w walks the segments [w*sspan, (w+1)*sspan), four loads in flight;
+            // the current source lives in registers and changes only when a segment index passes
+            // its last segment (wave-uniform compare, no search)
+            {
+                const int sspan = (SL + kDenseThreads / 64 - 1) / (kDenseThreads / 64);
+                int g = wave * sspan;
+                const int gend = (g + sspan < SL) ? g + sspan : SL;
+                if (g < gend) {
+                    int k = 0, hi_k = NL;                      // s_lseg[k] <= g < s_lseg[hi_k]
+                    while (hi_k - k > 1) {
+                        const int mid = (k + hi_k) >> 1;
+                        if (s_lseg[mid] <= g) k = mid; else hi_k = mid;
+                    }
+                    int seg0 = s_lseg[k], nxt = s_lseg[k + 1], lbs = s_lbs[k], llen = s_llen[k];
+                    for (; g < gend; g += 4) {
+                        int addr[4];
+                        bool ok[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int gg = g + u;
+                            const bool valid = gg < gend;
+                            while (valid && gg >= nxt) {       // uniform: next long source
+                                k++;
+                                seg0 = nxt;
+                                nxt = s_lseg[k + 1];
+                                lbs = s_lbs[k];
+                                llen = s_llen[k];
+                            }
+                            const int off = (gg - seg0) * 64 + lane;
+                            ok[u] = valid && off < llen;
+                            addr[u] = lbs + off;
+                        }
+                        int cv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) cv[u] = ok[u] ? Bcol[addr[u]] : -1;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const long long c = (long long)cv[u] - lo;
+                            if (ok[u] && c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                        }
+                    }
+                }
+            }
+            // short sources: their products evenly over the threads, 4 independent gathers in flight
             for (int p0 = tid; p0 < pb; p0 += 4 * kDenseThreads) {
                 int addr[4];
                 bool ok[4];
@@ -118,29 +171,50 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
             for (int t = tid; t < wwords; t += kDenseThreads) bmP[t] = 0ull;
             __syncthreads();
         }
-        // each thread owns `wpt` consecutive words: count, block-scan, emit in column order
-        const int w0 = tid * wpt;
-        const int w1 = (w0 + wpt < wwords) ? w0 + wpt : wwords;
+        // read-out in column order: wave w owns the words [w*wpw, (w+1)*wpw), lane l of a step the
+        // word l of the step's 64 -- a step's outputs are one contiguous piece of the row, written by
+        // a handful of store instructions that each touch the same few cache lines
+        const int wpw = ((wwords + 15) / 16 + 63) & ~63;
+        const int wbeg = wave * wpw;
+        const int wend = (wbeg + wpw < wwords) ? wbeg + wpw : wwords;
         int c = 0;
-        for (int w = w0; w < w1; w++) c += __popcll(bm[w]);
+        for (int w = wbeg + lane; w < wend; w += 64) c += __popcll(bm[w]);
         const int inc = wave_incl_scan(c);
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
-        int off = inc - c, btotal = 0;
+        int off = 0, btotal = 0;
         for (int k = 0; k < kDenseThreads / 64; k++) {
             const int t = wtot[k];
             if (k < wave) off += t;
             btotal += t;
         }
-        int pos = total + off;
-        for (int w = w0; w < w1; w++) {
-            u64 m = bm[w];
-            bm[w] = 0ull;
+        int run = total + off;                                 // wave-uniform output cursor
+        for (int w0 = wbeg; w0 < wend; w0 += 64) {
+            const int w = w0 + lane;
+            u64 m = 0ull;
+            if (w < wend) { m = bm[w]; bm[w] = 0ull; }
+            const int cw = __popcll(m);
+            const int iw = wave_incl_scan(cw);
+            int pos = run + iw - cw;
             const int base = (int)(lo + (long long)w * 64);
+            // dense words (hub columns: up to 64 bits set) are written by the whole wave, one word
+            // per store instruction, lane b holding bit b; the per-lane loop below then never runs
+            // longer than kDenseWordBits trips while the other lanes idle
+            u64 crowded = __ballot(cw >= kDenseWordBits);
+            while (crowded) {
+                const int src = (int)__builtin_ctzll(crowded);
+                crowded &= crowded - 1ull;
+                const u64 mw = wave_bcast64(m, src);
+                const int pw = wave_bcast(pos, src);
+                const int bw = wave_bcast(base, src);
+                if ((mw >> lane) & 1ull) out[pw + __popcll(mw & mask_lt(lane))] = bw | lane;
+            }
+            if (cw >= kDenseWordBits) m = 0ull;
             while (m) {
                 out[pos++] = base | (int)__builtin_ctzll(m);
                 m &= m - 1ull;
             }
+            run += wave_bcast(iw, 63);
         }
         total += btotal;
         __syncthreads();
