@@ -226,6 +226,8 @@ def main():
     bins = bin_of(F_row, caps)
     tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
     levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
+    if levels == 4 and n <= (512 << 15):
+        levels = 3                                                           # ... wave_levels_for_cols
     wave = (bins >= 1) & (bins < DENSE_BIN)
     bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
     ms_wave = float(phase_ms[2])

@@ -450,7 +450,7 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
     C->col_cap = totalF;
 
     // ---- numeric + stitch, pipelined over the super-tiles --------------------------------
-    const int levels = levels_for_cols(B->cols);
+    const int levels = wave_levels_for_cols(B->cols);
     size_t bin_start[kNumBins + 1] = {0, 0};               // class b's segment of rec[] (class 0 has none)
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
     int cls_n[kMaxTiles][kNumBins] = {};

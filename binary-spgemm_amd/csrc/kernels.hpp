@@ -37,6 +37,21 @@ inline int levels_for_cols(int64_t cols)
     return 5;
 }
 
+// k_wave_rows trades a fourth level for a larger top bitmap up to 2^24 columns (512 top words at
+// three levels): one ranked level costs two LDS reads, an atomic and a blocked scan per product
+// chunk, the larger top only a longer scan/clear per row (measured at 2^24 columns: -6 % kernel
+// time; 1024 words at 2^25 columns loses to four levels: too few resident waves).
+#ifndef BSP_WIDE_TOP
+#define BSP_WIDE_TOP 1
+#endif
+constexpr int kWaveTopWordsWide = 512;
+inline int wave_levels_for_cols(int64_t cols)
+{
+    const int L = levels_for_cols(cols);
+    if (BSP_WIDE_TOP && L == 4 && cols <= ((int64_t)kWaveTopWordsWide << 15)) return 3;
+    return L;
+}
+
 // one record per non-empty row, grouped by capacity class (written by the prepass)
 struct RowRec {
     int row;    // absolute row id

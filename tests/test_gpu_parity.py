@@ -141,9 +141,11 @@ def test_every_capacity_class_is_exercised(ctx):
     assert all(c > 0 for c in st["rows_per_bin"]), st["rows_per_bin"]
 
 
-@pytest.mark.parametrize("ncols", [40_000_000, 300_000_000], ids=["levels4_40M", "levels5_300M"])
+@pytest.mark.parametrize("ncols", [12_000_000, 40_000_000, 300_000_000],
+                         ids=["levels3_wide_top_12M", "levels4_40M", "levels5_300M"])
 def test_wide_columns(ctx, ncols):
-    """cols > 2^23 -> four 5-bit levels, cols > 2^28 -> five; B is 2000 x ncols"""
+    """2^23 < cols <= 2^24 -> three levels under a 512-word top bitmap, cols > 2^24 -> four 5-bit
+    levels, cols > 2^28 -> five; B is 2000 x ncols"""
     a_rp, a_ci = gen.uniform_rect(1500, 2000, 8, seed=401)
     rng = np.random.default_rng(402)
     rows = np.repeat(np.arange(2000), 30)
