@@ -1,5 +1,7 @@
 // kernels.hpp -- launch wrappers of the HIP kernels behind bspgemm_multiply (host-callable).
-// Kernel bodies: rowwork.hip, scan.hip, wave_rows.hip, dense_rows.hip, compact.hip.
+// Kernel bodies: prepass.hip (row work, scans, class records), wave_rows.inc (+ wave_rows_L*.hip),
+// wave_masked.hip, dense_rows.hip (heavy rows + compaction).  BSP_* macros are A/B switches for
+// tools/variants.sh; the defaults are the shipped configuration.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
