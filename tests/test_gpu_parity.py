@@ -174,6 +174,28 @@ def test_dense_rows_several_windows(ctx):
     assert st["rows_per_bin"][-1] >= 3
 
 
+def test_mostly_empty_rows(ctx):
+    """a result whose 32768-output compaction chunks span far more than 4096 rows (every 40th row
+    is non-empty): the per-output row search of k_compact; also the masked product of the same shape"""
+    n = 400_000
+    rng = np.random.default_rng(907)
+    live = np.arange(0, n, 40)
+    rows = np.repeat(live, 3)
+    cols = rng.choice(live, size=rows.size)                 # products land on non-empty rows of B = A
+    rp, ci = gen._csr_from_pairs(rows, cols, n)
+    erp, eci = O.spgemm(rp, ci, rp, ci, n)
+    crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
+    assert_same(crp, cci, erp, eci)
+    assert 0 < erp[-1] < 200_000 and st["rows_per_bin"][0] > 0.97 * n
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply_masked(A, A, A)
+    mrp, mci = C.download()
+    frp, fci = O.spgemm_masked(rp, ci, rp, ci, n, rp, ci)
+    assert_same(mrp, mci, frp, fci)
+    C.free()
+    A.free()
+
+
 def test_empty_and_degenerate(ctx):
     z = np.zeros(65, np.int32)
     crp, cci, _ = hip_product(ctx, z, np.zeros(0, np.int32), 64, z, np.zeros(0, np.int32), 64)
