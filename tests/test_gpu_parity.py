@@ -174,6 +174,46 @@ def test_dense_rows_several_windows(ctx):
     assert st["rows_per_bin"][-1] >= 3
 
 
+def test_fuzz_small_shapes(ctx):
+    """150 seeded random shapes against the oracle: rectangular, skewed, duplicate-heavy, column
+    counts on every side of the level boundaries (8192, 2^18, 2^23, 2^24), row ranges, masks"""
+    rng = np.random.default_rng(20261004)
+    col_choices = [1, 7, 64, 65, 1000, 8192, 8193, 50_000, 262_144, 262_145, 3_000_000, 8_388_608, 8_388_609,
+                   16_777_216, 16_777_217, 100_000_000]
+    for case in range(150):
+        ar = int(rng.integers(1, 400))
+        inner = int(rng.integers(1, 400))
+        ncols = int(col_choices[int(rng.integers(0, len(col_choices)))])
+        da = int(rng.integers(0, 12))
+        db = int(rng.choice([0, 1, 3, 17, 80, 300]))
+        # A: ar x inner, B: inner x ncols; a few hub rows in both
+        a_rows = np.concatenate([np.repeat(np.arange(ar), da), np.zeros(int(rng.integers(0, 200)), np.int64)])
+        a_cols = rng.integers(0, inner, size=a_rows.size)
+        b_rows = np.concatenate([np.repeat(np.arange(inner), db), np.full(int(rng.integers(0, 3000)), inner - 1)])
+        span = ncols if rng.random() < 0.5 else min(ncols, 97)          # narrow span -> many duplicates
+        b_cols = rng.integers(0, span, size=b_rows.size)
+        a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, ar, dedup=bool(case & 1))
+        b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, inner, dedup=bool(case & 2))
+        r0 = int(rng.integers(0, ar)) if case % 5 == 0 else 0
+        r1 = int(rng.integers(r0, ar + 1)) if case % 5 == 0 else ar
+        erp, eci = O.spgemm_rows(a_rp, a_ci, b_rp, b_ci, ncols, r0, r1)
+        crp, cci, _ = hip_product(ctx, a_rp, a_ci, inner, b_rp, b_ci, ncols, r0, r1)
+        assert_same(crp, cci, erp, eci)
+        if case % 4 == 0:                                               # masked with a random mask
+            f_rows = np.repeat(np.arange(ar), int(rng.integers(1, 40)))
+            f_cols = rng.integers(0, span, size=f_rows.size)
+            f_rp, f_ci = gen._csr_from_pairs(f_rows, f_cols, ar)
+            mrp, mci = O.spgemm_masked(a_rp, a_ci, b_rp, b_ci, ncols, f_rp, f_ci)
+            A = ctx.upload(a_rp, a_ci, inner)
+            B = ctx.upload(b_rp, b_ci, ncols)
+            Fm = ctx.upload(f_rp, f_ci, ncols)
+            C = ctx.multiply_masked(A, B, Fm)
+            grp, gci = C.download()
+            assert_same(grp, gci, mrp, mci)
+            for h in (C, A, B, Fm):
+                h.free()
+
+
 def test_mostly_empty_rows(ctx):
     """a result whose 32768-output compaction chunks span far more than 4096 rows (every 40th row
     is non-empty): the per-output row search of k_compact; also the masked product of the same shape"""
