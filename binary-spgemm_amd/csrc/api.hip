@@ -464,12 +464,15 @@ static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *
     for (int k = 0; k < T && R > 0; k++) {
         const int *bt0 = ctx->h_bin_tiles + (size_t)tile_index(tb[k]) * kNumBins;
         const int *bt1 = ctx->h_bin_tiles + (size_t)tile_index(tb[k + 1]) * kNumBins;
-        for (int b = 1; b < kNumBins; b++) {
+        for (int pos = 1; pos < kNumBins; pos++) {
+            // launch order: the heavy rows first (few long-running workgroups: started early they
+            // finish under the other classes instead of being the multiply's tail), then the
+            // one-wave classes by capacity
+            const int b = pos == 1 ? kDenseBin : pos - 1;
             const int n = bt1[b] - bt0[b];
             cls_n[k][b] = n;
             if (n <= 0) continue;
-            // the two heaviest classes go to different streams so that every tile keeps the chip full
-            hipStream_t sx = lanes[b % nlanes];
+            hipStream_t sx = lanes[pos % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
             const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
             HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));

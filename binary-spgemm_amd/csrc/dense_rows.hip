@@ -233,12 +233,15 @@ static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, c
     if (words > max_words) words = max_words;
     if (words < 1) words = 1;
     const int bytes = (int)words * 8 * (MASKED ? 2 : 1);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (kernel, device) pair: a process may hold contexts on several GPUs
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_rows<MASKED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_dense_rows<MASKED>), dim3(nrows), dim3(kDenseThreads), bytes, s, ab, Bcol,
                        cols, (int)words, rec, recpre, row_begin, tmp, cnt, Frow, Fcol);
