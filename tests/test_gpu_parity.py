@@ -214,6 +214,26 @@ def test_fuzz_small_shapes(ctx):
                 h.free()
 
 
+@pytest.mark.parametrize("env", [{"BSPGEMM_TILES": "4"}, {"BSPGEMM_CLASS_STREAMS": "1"}, {"BSPGEMM_CLASS_STREAMS": "3"}],
+                         ids=["row_tiles_4", "one_stream", "three_streams"])
+def test_tuning_knobs_do_not_change_results(ctx, env):
+    """the stream/tile knobs only reorder launches; 300 K rows so that tiles engage"""
+    rp, ci, n = gen.uniform(300_000, 4, 915)
+    erp, eci = O.spgemm(rp, ci, rp, ci, n)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert_same(crp, cci, erp, eci)
+    assert st["tiles"] == int(env.get("BSPGEMM_TILES", 1))
+
+
 def test_mostly_empty_rows(ctx):
     """a result whose 32768-output compaction chunks span far more than 4096 rows (every 40th row
     is non-empty): the per-output row search of k_compact; also the masked product of the same shape"""
