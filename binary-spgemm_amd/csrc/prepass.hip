@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
         // U nonzeros per lane and trip: their A.col_idx loads, then their B.row_ptr gathers, are
         // issued together (independent misses in flight instead of one dependent chain per nonzero)
         constexpr int U = BSP_RW_UNROLL;
-        for (int jj = a0 + sub; jj < a1; jj += 8 * U) {
+        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {      // 64-bit: jj + 8u may pass INT_MAX
             int j[U];
 #pragma unroll
             for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
