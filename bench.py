@@ -208,59 +208,64 @@ def main():
     bin_ms /= args.steps
     phase_ms /= args.steps
 
-    # ---- roofline of the dominant kernel (this rank's launches) -------------------------
-    # The dominant kernel is k_wave_rows (csrc/wave_rows.inc): ONE kernel source, launched as one
-    # template instance per capacity class (16 of them), back to back on two streams so that one
-    # instance's tail overlaps the next one's ramp-up.  Its "launch" is therefore the whole family:
-    # algorithmic bytes of all one-wave rows (4 B/product + 4 B/output nonzero +
-    # 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start to the
-    # last one's end on the multiply's stream (bspgemm_stats.ms_numeric, which also holds the few
-    # heavy rows of k_dense_rows and the count scan: conservative).  Per-instance event brackets are
-    # listed next to it; they overlap pairwise, so their sum exceeds the family's time.
-    crp, _ = last.download(col_idx=False)
-    F_row = np.diff(prefix)[r0:r1]
-    a_row = np.diff(rp.astype(np.int64))[r0:r1]
-    c_row = np.diff(crp)
-    caps = st["bin_cap"]
-    DENSE_BIN = len(caps) - 1
-    bins = bin_of(F_row, caps)
-    tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
-    levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
-    if levels == 4 and n <= (512 << 15):
-        levels = 3                                                           # ... wave_levels_for_cols
-    wave = (bins >= 1) & (bins < DENSE_BIN)
-    bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
-    ms_wave = float(phase_ms[2])
-    achieved = bytes_wave / (ms_wave * 1e-3) / 1e9 if ms_wave > 0 else 0.0
-    instances = []
-    for b in range(1, DENSE_BIN):
-        selb = bins == b
-        if selb.any():
-            instances.append({"chunks": caps[b] // 64, "rows": int(selb.sum()), "products": int(F_row[selb].sum()),
-                              "ms": round(float(bin_ms[b]) / tiles, 4)})
-    # HBM traffic: PMC counters cannot be read from inside the process, so the committed
-    # rocprofv3 --pmc result of this very command is quoted when the workload is the profiled one
-    # (tools/pmc_run.sh -> profiles/*_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE summed over the
-    # family's instances); otherwise null.
-    traffic, traffic_src = None, None
     try:
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-            prof = json.load(open(path))
-            fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
-            if prof.get("workload") == wname and world == 1 and tiles == 1 and len(fam) == len(instances):
-                traffic = int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))
-                traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE of the %d instances, uncorrected)" % len(fam)
-                break
-    except Exception:
-        traffic = None
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_wave_rows<LEVELS=%d,*> (%d capacity-class instances, two streams)" % (levels, len(instances)),
-                "bytes_per_launch": bytes_wave, "ms_per_launch": round(ms_wave, 4),
-                "launch_rows": int(wave.sum()), "launch_products": int(F_row[wave].sum()),
-                "instances": instances}
+        # ---- roofline of the dominant kernel (this rank's launches) -------------------------
+        # The dominant kernel is k_wave_rows (csrc/wave_rows.inc): ONE kernel source, launched as one
+        # template instance per capacity class (16 of them), back to back on two streams so that one
+        # instance's tail overlaps the next one's ramp-up.  Its "launch" is therefore the whole family:
+        # algorithmic bytes of all one-wave rows (4 B/product + 4 B/output nonzero +
+        # 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start to the
+        # last one's end on the multiply's stream (bspgemm_stats.ms_numeric, which also holds the few
+        # heavy rows of k_dense_rows and the count scan: conservative).  Per-instance event brackets are
+        # listed next to it; they overlap pairwise, so their sum exceeds the family's time.
+        crp, _ = last.download(col_idx=False)
+        F_row = np.diff(prefix)[r0:r1]
+        a_row = np.diff(rp.astype(np.int64))[r0:r1]
+        c_row = np.diff(crp)
+        caps = st["bin_cap"]
+        DENSE_BIN = len(caps) - 1
+        bins = bin_of(F_row, caps)
+        tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
+        levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
+        if levels == 4 and n <= (512 << 15):
+            levels = 3                                                           # ... wave_levels_for_cols
+        wave = (bins >= 1) & (bins < DENSE_BIN)
+        bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
+        ms_wave = float(phase_ms[2])
+        achieved = bytes_wave / (ms_wave * 1e-3) / 1e9 if ms_wave > 0 else 0.0
+        instances = []
+        for b in range(1, DENSE_BIN):
+            selb = bins == b
+            if selb.any():
+                instances.append({"chunks": caps[b] // 64, "rows": int(selb.sum()), "products": int(F_row[selb].sum()),
+                                  "ms": round(float(bin_ms[b]) / tiles, 4)})
+        # HBM traffic: PMC counters cannot be read from inside the process, so the committed
+        # rocprofv3 --pmc result of this very command is quoted when the workload is the profiled one
+        # (tools/pmc_run.sh -> profiles/*_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE summed over the
+        # family's instances); otherwise null.
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+                prof = json.load(open(path))
+                fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
+                if prof.get("workload") == wname and world == 1 and tiles == 1 and len(fam) == len(instances):
+                    traffic = int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))
+                    traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE of the %d instances, uncorrected)" % len(fam)
+                    break
+        except Exception:
+            traffic = None
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "k_wave_rows<LEVELS=%d,*> (%d capacity-class instances, two streams)" % (levels, len(instances)),
+                    "bytes_per_launch": bytes_wave, "ms_per_launch": round(ms_wave, 4),
+                    "launch_rows": int(wave.sum()), "launch_products": int(F_row[wave].sum()),
+                    "instances": instances}
 
+    except Exception as e:   # the roofline is a reported extra: never lose the metric line to it
+        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "error": "%s: %s" % (type(e).__name__, e)}
+        caps = list(st.get("bin_cap", []))
     ms_per_step = elapsed / args.steps * 1e3
     value = nnz_total * args.steps / elapsed / 1e9
     out = {
