@@ -140,6 +140,7 @@ def main():
     if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
         os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 16) // world)))
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see bspgemm/__init__.py: RCCL's streams must not crowd ours
     import torch
     import torch.distributed as dist
     import bspgemm
@@ -169,9 +170,9 @@ def main():
 
     def step():
         C = ctx.multiply(A, A, r0, r1)
-        if use_dist:
+        if use_dist and os.environ.get("BSPGEMM_BENCH_NO_STITCH") != "1":   # (switch for overhead hunting)
             local_rp = bdist.device_tensor(C.row_ptr_device, C.rows + 1, torch.int64, dev)
-            bdist.stitch_row_ptr(local_rp, bounds)
+            bdist.stitch_row_ptr(local_rp, bounds, detach=False, ctx=ctx)   # C stays alive for two steps
         return C
 
     def fence():
@@ -186,16 +187,21 @@ def main():
     phase_ms = np.zeros(4)
     fence()
     t_start = time.perf_counter()
-    last = None
+    last = older = None
     for _ in range(args.steps):
-        if last is not None:
-            last.free()
+        # two results stay alive: the stitch of step k-1 (asynchronous, torch's stream) may still be
+        # reading C(k-1).row_ptr when step k starts; it has long finished when step k+1 reuses the buffer
+        if older is not None:
+            older.free()
+        older = last
         last = step()
         st = ctx.stats()
         bin_ms = np.array(st["ms_bin"]) if bin_ms is None else bin_ms + np.array(st["ms_bin"])
         phase_ms += np.array([st["ms_total"], st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"]])
     fence()
     elapsed = time.perf_counter() - t_start
+    if older is not None:
+        older.free()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -50,12 +50,15 @@ def device_tensor(ptr, n, dtype, device):
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
 
 
-def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True):
+def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True, ctx=None):
     """All-gather the shards' row lengths and rebuild the global C.row_ptr on every rank.
 
     local_row_ptr : int64 tensor [rows_r + 1], slice-local (starts at 0) -- on the GPU for
                     backend nccl, on the CPU for gloo.
     bounds        : int array [world+1], the shard row bounds every rank used.
+    ctx           : bspgemm.Context of this GPU: the gathered lengths are then scanned into the
+                    row_ptr by the library's own kernels (bspgemm_lengths_to_row_ptr) on torch's
+                    stream; without it (CPU tensors, gloo) the same arithmetic runs as torch ops.
     detach        : wait (host side) until the send buffer has been built from `local_row_ptr`, so
                     that the caller may release or overwrite it while the collective is in flight
                     (the collective itself stays asynchronous on torch's stream).
@@ -73,7 +76,7 @@ def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True):
     assert local_row_ptr.numel() == rows[rank] + 1, "local row_ptr does not match bounds[rank]"
     width = max(int(rows.max()), 1)
     dev = local_row_ptr.device
-    send = torch.zeros(width, dtype=torch.int32, device=dev)
+    send = torch.empty(width, dtype=torch.int32, device=dev)    # the pad slots are never read
     send[: rows[rank]] = (local_row_ptr[1:] - local_row_ptr[:-1]).to(torch.int32)
     if detach and local_row_ptr.is_cuda:
         torch.cuda.current_stream(dev).synchronize()
@@ -82,11 +85,16 @@ def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True):
         dist.all_gather_into_tensor(recv, send, group=group)
     else:
         _all_gather_list(recv, send, world, group)
-    recv = recv.view(world, width)
-    out = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-    for r in range(world):
-        out[1 + int(bounds[r]): 1 + int(bounds[r + 1])] = recv[r, : int(rows[r])]
-    out = torch.cumsum(out, 0)
+    if ctx is not None and local_row_ptr.is_cuda:
+        out = torch.empty(R + 1, dtype=torch.int64, device=dev)
+        ctx.lengths_to_row_ptr(recv.data_ptr(), world, width, bounds, out.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        recv = recv.view(world, width)
+        out = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        for r in range(world):
+            out[1 + int(bounds[r]): 1 + int(bounds[r + 1])] = recv[r, : int(rows[r])]
+        out = torch.cumsum(out, 0)
     edges = torch.as_tensor(bounds, dtype=torch.int64, device=dev)
     shard_nnz = out[edges[1:]] - out[edges[:-1]]
     return out, shard_nnz

@@ -85,6 +85,8 @@ struct bspgemm_context {
     hipEvent_t ev_tile[kMaxTiles][3] = {};          // per super-tile: classes on stream_b done / scan done / start fence
     hipEvent_t ev_cls[kMaxTiles][kNumBins][2] = {}; // per (super-tile, class): launch brackets
     hipEvent_t ev_join = nullptr;
+    long long *stitch_partials = nullptr;           // scan scratch of bspgemm_lengths_to_row_ptr
+    size_t stitch_partials_cap = 0;
     int *h_bin_tiles = nullptr;         // pinned copy of bin_tiles
     size_t h_bin_tiles_cap = 0;
     // per-row workspace (capacity rows_cap rows)
@@ -181,6 +183,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     if (ctx->stream_b) { hipStreamSynchronize(ctx->stream_b); hipStreamDestroy(ctx->stream_b); }
     if (ctx->stream_c) { hipStreamSynchronize(ctx->stream_c); hipStreamDestroy(ctx->stream_c); }
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    hipFree(ctx->stitch_partials);
     for (auto &t : ctx->ev_tile) for (auto &e : t) if (e) hipEventDestroy(e);
     for (auto &t : ctx->ev_cls) for (auto &c : t) for (auto &e : c) if (e) hipEventDestroy(e);
     if (ctx->h_bin_tiles) hipHostFree(ctx->h_bin_tiles);
@@ -609,6 +612,33 @@ extern "C" bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm
 {
     if (!ctx || !out || !ctx->stats_valid) return FAIL(BSPGEMM_ERR_INVALID, "no multiply has run on this context");
     *out = ctx->stats;
+    return BSPGEMM_OK;
+}
+
+// --------------------------------------------------------------- gathered lengths -> row_ptr -
+extern "C" bspgemm_status bspgemm_lengths_to_row_ptr(bspgemm_context *ctx, const int *d_lengths, int nranks, int width,
+                                                     const int *bounds, int64_t *d_row_ptr, void *hip_stream)
+{
+    if (!ctx || !d_lengths || !bounds || !d_row_ptr || nranks < 1 || width < 0 || bounds[0] != 0)
+        return FAIL(BSPGEMM_ERR_INVALID, "lengths_to_row_ptr");
+    for (int r = 0; r < nranks; r++)
+        if (bounds[r + 1] < bounds[r] || bounds[r + 1] - bounds[r] > width) return FAIL(BSPGEMM_ERR_INVALID, "bounds");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);      // NULL is HIP's default stream, as for any launch
+    // own scan scratch: this may run on another stream than a multiply that is using ctx->partials
+    const size_t need = (size_t)width / 2048 + 2;
+    if (need > ctx->stitch_partials_cap) {
+        if (ctx->stitch_partials) HIPCHK(hipFree(ctx->stitch_partials));
+        ctx->stitch_partials = nullptr;
+        ctx->stitch_partials_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->stitch_partials), need * sizeof(long long)));
+        ctx->stitch_partials_cap = need;
+    }
+    long long *out = reinterpret_cast<long long *>(d_row_ptr);
+    for (int r = 0; r < nranks; r++)          // shard r continues the row_ptr where shard r-1 ended
+        launch_scan_counts(d_lengths + (size_t)r * width, bounds[r + 1] - bounds[r], out + bounds[r],
+                           ctx->stitch_partials, r == 0 ? nullptr : out + bounds[r], s);
+    HIPCHK(hipGetLastError());
     return BSPGEMM_OK;
 }
 

@@ -60,6 +60,9 @@ static int cmp_double(const void *a, const void *b)
 
 int main(int argc, char **argv)
 {
+    /* before anything touches the HIP runtime: enough hardware queues for the library's three
+     * streams next to RCCL's (tuning knobs) */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int numtasks = 1, rank = 0;
 #ifdef BSPGEMM_WITH_MPI
     int provided;

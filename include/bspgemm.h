@@ -196,6 +196,14 @@ bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES])
 bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[BSPGEMM_UNIQUE_ID_BYTES],
                                    int rank, int nranks, bspgemm_comm **comm);
 void           bspgemm_comm_destroy(bspgemm_comm *comm);
+/* Second half of a stitch whose collective ran elsewhere (bspgemm/dist.py: torch.distributed):
+ * `d_lengths` holds the all-gathered int32 row lengths, rank-major, `width` slots per rank of
+ * which bounds[r+1]-bounds[r] are used; writes the global int64 row_ptr (bounds[nranks]+1
+ * entries) on the device.  Enqueued on `hip_stream` (a hipStream_t; NULL = HIP's default
+ * stream) -- pass the stream the collective was issued on; the context's own stream is not used.  Replaces the serial rebase of final/SpGEMM_mpi_omp.c:
+ * 213-223.                                                                                    */
+bspgemm_status bspgemm_lengths_to_row_ptr(bspgemm_context *ctx, const int *d_lengths, int nranks, int width,
+                                          const int *bounds, int64_t *d_row_ptr, void *hip_stream);
 /* All-gather and rebase: `bounds[nranks+1]` are the shard row bounds every rank used; `local`
  * is this rank's product of rows [bounds[rank],bounds[rank+1]).  On return *d_row_ptr_global
  * points at a device buffer owned by `comm` (bounds[nranks]+1 int64, valid until the next

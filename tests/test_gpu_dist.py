@@ -68,6 +68,21 @@ def test_torch_rccl_stitch_one_rank():
         assert np.array_equal(local.cpu().numpy(), crp)
         g, shard = bdist.stitch_row_ptr(local, bounds)
         assert np.array_equal(g.cpu().numpy(), crp) and int(shard[0]) == crp[-1]
+        g2, shard2 = bdist.stitch_row_ptr(local, bounds, ctx=ctx)        # lengths scanned by the library
+        assert np.array_equal(g2.cpu().numpy(), crp) and int(shard2[0]) == crp[-1]
+        # the library half alone, on a made-up 3-rank gather with ragged shards (one of them empty)
+        lens = np.diff(crp).astype(np.int32)
+        fake_bounds = np.array([0, 5000, 5000, n], dtype=np.int32)
+        width = int(np.diff(fake_bounds).max())
+        padded = np.zeros((3, width), dtype=np.int32)
+        for r in range(3):
+            padded[r, : fake_bounds[r + 1] - fake_bounds[r]] = lens[fake_bounds[r]: fake_bounds[r + 1]]
+        padded[1, :] = 7                                                 # pad slots must be ignored
+        d_len = torch.from_numpy(padded).to(dev)
+        out = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        ctx.lengths_to_row_ptr(d_len.data_ptr(), 3, width, fake_bounds, out.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream)
+        assert np.array_equal(out.cpu().numpy(), crp)
         ctx.close()
     finally:
         dist.destroy_process_group()
