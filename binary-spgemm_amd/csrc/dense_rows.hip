@@ -273,6 +273,10 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
 constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
+#ifndef BSP_COMPACT_INFLIGHT
+#define BSP_COMPACT_INFLIGHT 4
+#endif
+constexpr int kCompactInFlight = BSP_COMPACT_INFLIGHT;   // 16-B groups a thread has in flight
 constexpr int kCompactSparseRows = 4096; // a chunk spanning more rows than this is searched per output
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
@@ -335,13 +339,13 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
         __syncthreads();
         const long long b0 = rp[0] > o0 ? rp[0] : o0;          // outputs covered by this batch and chunk
         const long long b1 = rp[nb] < o1 ? rp[nb] : o1;
-        // two 16-B groups per thread per step: independent row searches and loads in flight
-        for (long long g0 = (b0 >> 2) + tid; (g0 << 2) < b1; g0 += 512) {
-            long long o[2], src[2];
-            bool fast[2], live[2];
-            int lo_r[2];
+        // kCompactInFlight 16-B groups per thread per step: independent row searches and loads in flight
+        for (long long g0 = (b0 >> 2) + tid; (g0 << 2) < b1; g0 += 256 * kCompactInFlight) {
+            long long o[kCompactInFlight], src[kCompactInFlight];
+            bool fast[kCompactInFlight], live[kCompactInFlight];
+            int lo_r[kCompactInFlight];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < kCompactInFlight; u++) {
                 const long long g = g0 + u * 256;
                 o[u] = g << 2;
                 live[u] = o[u] < b1;
@@ -355,12 +359,12 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                 fast[u] = live[u] && o[u] >= b0 && o[u] + 3 < b1 && o[u] + 3 < rp[lo + 1];
                 src[u] = o[u] + sh[lo];
             }
-            Int4U v[2];
+            Int4U v[kCompactInFlight];
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < kCompactInFlight; u++)
                 if (fast[u]) v[u] = *reinterpret_cast<const Int4U *>(tmp + src[u]);     // source only dword aligned
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < kCompactInFlight; u++) {
                 if (fast[u]) {
                     const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
                     __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
