@@ -243,8 +243,11 @@ def main():
         for b in range(1, DENSE_BIN):
             selb = bins == b
             if selb.any():
+                by = int(4 * F_row[selb].sum() + 4 * c_row[selb].sum() + 12 * a_row[selb].sum() + 12 * selb.sum())
+                ms_b = float(bin_ms[b]) / tiles
                 instances.append({"chunks": caps[b] // 64, "rows": int(selb.sum()), "products": int(F_row[selb].sum()),
-                                  "ms": round(float(bin_ms[b]) / tiles, 4)})
+                                  "bytes": by, "ms": round(ms_b, 4),          # ms: event bracket = rocprofv3 average
+                                  "GBps_while_sharing_the_gpu": round(by / (ms_b * 1e-3) / 1e9, 1) if ms_b > 0 else 0.0})
         # HBM traffic: PMC counters cannot be read from inside the process, so the committed
         # rocprofv3 --pmc result of this very command is quoted when the workload is the profiled one
         # (tools/pmc_run.sh -> profiles/*_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE summed over the
