@@ -2,18 +2,21 @@
 """bench.py -- headline benchmark: boolean SpGEMM C = A*A, output nonzeros per second.
 
 A "step" is one full pass of the hot path over one synthetic matrix that is already resident
-in HBM: bspgemm_multiply (row work -> scan/bin -> accumulate+emit -> scan -> compaction) on this
-rank's A-row shard, plus, for N > 1, the all-gather that stitches C.row_ptr (the job of
-SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  The timed region mirrors the
-reference's (:320-324): inputs resident, result allocation included, no file I/O.
+in HBM: bspgemm_multiply (row work -> classes -> exact row sizes -> scan = C.row_ptr -> every row
+emitted at its final place) on this rank's A-row shard, plus, for N > 1, the all-gather that
+stitches C.row_ptr (the job of SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  The timed
+region mirrors the reference's (:320-324): inputs resident, result allocation included, no file I/O.
 
-Workload at N = 1: BASELINE.json configs[2], the config the north-star target is quoted on --
-R-MAT scale 22, edge factor 16, (a,b,c,d) = (0.30,0.25,0.25,0.20), A*A.
-For N GPUs the scale is 22 + log2(N) (rows, nonzeros and products all double per step, so the
-work per GPU is fixed: weak scaling); rows are cut into N contiguous shards of equal work, B = A
-is replicated on every GPU.
+Workloads (BASELINE.json configs, R-MAT edge factor 16, (a,b,c,d) = (0.30,0.25,0.25,0.20), seed 1,
+SURVEY.md 8d/9.2):
+    --gpus 1          configs[2]: scale 22 -- the config the north-star target is quoted on
+    --gpus N (N > 1)  configs[3]: scale 24 row-sharded over the N GPUs, B replicated; the total
+                      work is fixed, so "scaling": "strong"
+    --gpus N --weak   scale 22 + log2 N: rows, nonzeros and products double with N, the work per
+                      GPU is fixed ("scaling": "weak")
+Rows are cut into N contiguous shards of equal work; B = A is replicated on every GPU.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (spawns its N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -22,6 +25,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,10 +35,9 @@ for p in (ROOT, os.path.join(ROOT, "binary-spgemm_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 RMAT_MILD = (0.30, 0.25, 0.25)  # d = 0.20
+MAX_STAT_STEPS = 16             # event sets the library keeps (bspgemm_stats_at)
 
 
 def log(rank, *a):
@@ -41,10 +45,55 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="rmat", choices=["rmat", "rmat-g500", "uniform", "powerlaw"])
+    ap.add_argument("--scale", type=int, default=0)
+    ap.add_argument("--weak", action="store_true", help="N > 1: scale 22 + log2 N instead of BASELINE cfg4 (scale 24)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (this
+    process has not touched the GPU and never will), relay rank 0's JSON line, return the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) // args.gpus))))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def pick_scale(args, world):
+    """(scale, scaling) of the R-MAT workload -- see the module docstring"""
+    if args.scale:
+        return args.scale, ("weak" if args.weak else "strong")
+    if world == 1:
+        return 22, "weak"                       # one GPU: both readings coincide
+    if args.weak:
+        return 22 + int(round(math.log2(world))), "weak"
+    return 24, "strong"
+
+
 def make_matrix(args, world):
     import bspgemm
+    scaling = "strong"                           # a fixed matrix whatever N is ...
     if args.workload == "rmat":
-        scale = args.scale if args.scale else 22 + int(round(math.log2(world)))
+        scale, scaling = pick_scale(args, world)  # ... except the weak-scaling R-MAT series
         rp, ci, n = bspgemm.gen_rmat(scale, 16, RMAT_MILD, seed=1)
         name = "R-MAT scale %d, edge factor 16, (a,b,c,d)=(0.30,0.25,0.25,0.20), seed 1, A*A" % scale
     elif args.workload == "rmat-g500":
@@ -61,12 +110,13 @@ def make_matrix(args, world):
         name = "power-law n=2^%d, mean degree 64 (Pareto 2.1, clip n/16), seed 1, A*A" % scale
     else:
         raise SystemExit("unknown workload " + args.workload)
-    return rp, ci, n, name
+    return rp, ci, n, name, scaling
 
 
 def bin_of(F, caps):
     """capacity class of a row with F products -- same rule as csrc/prepass.hip bin_of(); `caps` is
     bspgemm_stats.bin_cap: caps[0] = 0 (empty rows), caps[-1] = INT32_MAX (heavy rows)"""
+    import numpy as np
     b = np.zeros(F.shape, dtype=np.int64)
     b[F > 0] = 1
     for k in range(1, len(caps) - 1):
@@ -74,54 +124,75 @@ def bin_of(F, caps):
     return b
 
 
-def cpu_baseline(rp, ci, n, budget_s=12.0):
-    """Reference CPU path (oracle/_ref SpGEMM_omp, else the in-repo port) on a bounded row sample."""
+def cpu_baseline(rp, ci, n, budget_s=6.0):
+    """Reference CPU path -- the reference's own SpGEMM_omp compiled into oracle/_ref (kind
+    "reference"; the in-repo port when that is absent) -- on bounded row samples of the same matrix,
+    with the OpenMP team set explicitly (omp_set_num_threads) to 1, C/2 and C threads."""
+    import ctypes
     from oracle import oracle as O
-    cores = min(16, len(os.sched_getaffinity(0)))     # one GPU's CPU share on the box
     R = O.reference()
     kind = "reference" if R is not None else "port"
+    gomp = ctypes.CDLL("libgomp.so.1", mode=ctypes.RTLD_GLOBAL)     # the runtime oracle/_ref links: one per process
+    host_cpus = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0))
+    C = min(16, usable)                     # one GPU's CPU share on the box
 
-    def run(row0, rows, tblock):
+    def run(threads, row0, rows):
+        unit = threads * 8                  # decomposition stays divisible (reference README.md:14)
+        rows -= rows % unit
+        if rows <= 0:
+            return None
+        tblock = rows // unit
+        gomp.omp_set_num_threads(int(threads))
+        team = int(gomp.omp_get_max_threads())
         t = time.perf_counter()
         if R is not None:
-            crow, ccol = R.omp(rp, ci, rp, ci, n, tblock, row0=row0, rows=rows)
+            crow, _ = R.omp(rp, ci, rp, ci, n, tblock, row0=row0, rows=rows)
         else:
-            crow, ccol = O.spgemm_omp(rp, ci, rp, ci, n, tblock, cores, row0=row0, rows=rows)
-        return time.perf_counter() - t, int(crow[-1])
+            crow, _ = O.spgemm_omp(rp, ci, rp, ci, n, tblock, threads, row0=row0, rows=rows)
+        dt = time.perf_counter() - t
+        return {"threads": int(threads), "omp_get_max_threads": team, "rows": int(rows), "row0": int(row0),
+                "tBlock": int(tblock), "nnz": int(crow[-1]), "seconds": round(dt, 3),
+                "GNZ/s": round(int(crow[-1]) / dt / 1e9, 5)}
 
     row0 = n // 2
-    unit = cores * 8                       # keep the decomposition divisible (reference README.md:14)
-    rows = min(unit * 64, n - row0)
-    rows -= rows % unit
-    if rows <= 0:
+    probe = run(C, row0, min(C * 8 * 64, n - row0))
+    if probe is None:
         return None
-    dt, nnz = run(row0, rows, max(rows // unit, 1))
-    for _ in range(3):                     # grow the sample until it is ~budget_s of CPU work
-        if dt >= 0.6 * budget_s or row0 + rows >= n:
-            break
-        per_row = max(nnz / rows, 1.0)
-        grow = min(budget_s / max(dt, 1e-3), 16.0)
-        new_rows = int(min(n - row0, rows * grow, 1.5e9 / per_row))   # int32 nnz of the reference
-        new_rows -= new_rows % unit
-        if new_rows <= rows:
-            break
-        rows = new_rows
-        dt, nnz = run(row0, rows, rows // unit)
-    tblock = rows // unit
-    return {"value": round(nnz / dt / 1e9, 5), "unit": "GNZ/s", "cores": cores, "kind": kind,
-            "sample": "rows [%d,%d) of the same matrix (%d output nonzeros), SpGEMM_omp with %d OpenMP "
-                      "threads, tBlock=%d, %.2f s" % (row0, row0 + rows, nnz, cores, tblock, dt)}
+    per_row_s = probe["seconds"] / probe["rows"] * C      # core-seconds per row
+    sweep = []
+    for t in sorted({1, max(C // 2, 1), C}):
+        rows = int(min(n - row0, budget_s * t / max(per_row_s, 1e-9), 1.5e9 / max(probe["nnz"] / probe["rows"], 1.0)))
+        r = run(t, row0, rows)
+        if r:
+            sweep.append(r)
+    best = max(sweep, key=lambda r: r["GNZ/s"])
+    return {"value": best["GNZ/s"], "unit": "GNZ/s", "cores": best["omp_get_max_threads"], "kind": kind,
+            "sample": "rows [%d,%d) of the same matrix (%d output nonzeros), SpGEMM_omp, omp_set_num_threads(%d), "
+                      "tBlock=%d, %.2f s" % (best["row0"], best["row0"] + best["rows"], best["nnz"], best["threads"],
+                                             best["tBlock"], best["seconds"]),
+            "thread_sweep": sweep, "host_cpus": host_cpus, "usable_cpus": usable}
+
+
+def pmc_profile(wname, world):
+    """the committed rocprofv3 --pmc result of this very command (tools/pmc_run.sh -> profiles/*_pmc_traffic.json)"""
+    import glob
+    if world != 1:
+        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except Exception:
+            continue
+        if prof.get("workload") == wname:
+            return prof, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="rmat", choices=["rmat", "rmat-g500", "uniform", "powerlaw"])
-    ap.add_argument("--scale", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))            # before anything in this process touches the GPU
 
     # Only the JSON line may reach stdout: RCCL prints a version banner there when the first
     # communicator is created.  Everything else is sent to stderr for the whole run.
@@ -133,14 +204,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     # torch.distributed.run exports OMP_NUM_THREADS=1 for every rank; the host-side generators
-    # (OpenMP, csr_gen.c) would then build the scale-25 matrix on one core.  Give each rank its share.
+    # (OpenMP, csr_gen.c) would then build the matrix on one core.  Give each rank its share.
     if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
         os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, (os.cpu_count() or 16) // world)))
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see bspgemm/__init__.py: RCCL's streams must not crowd ours
+    import numpy as np
     import torch
     import torch.distributed as dist
     import bspgemm
@@ -158,8 +230,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t0 = time.perf_counter()
-    rp, ci, n, wname = make_matrix(args, world)
-    log(rank, "generated %s: n=%d nnz(A)=%d in %.1f s" % (wname, n, rp[-1], time.perf_counter() - t0))
+    rp, ci, n, wname, scaling = make_matrix(args, world)
+    log(rank, "generated %s: n=%d nnz(A)=%d in %.1f s; scaling=%s" % (wname, n, rp[-1], time.perf_counter() - t0, scaling))
 
     ctx = bspgemm.Context(local_rank)
     A = ctx.upload(rp, ci, n)                       # B = A, replicated on every GPU
@@ -168,12 +240,23 @@ def main():
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     log(rank, "F=%d products; shard bounds %s" % (prefix[-1], bounds.tolist()))
 
+    stitch_done = []                                # events: stitch k has finished reading C(k).row_ptr
+
     def step():
         C = ctx.multiply(A, A, r0, r1)
         if use_dist and os.environ.get("BSPGEMM_BENCH_NO_STITCH") != "1":   # (switch for overhead hunting)
             local_rp = bdist.device_tensor(C.row_ptr_device, C.rows + 1, torch.int64, dev)
-            bdist.stitch_row_ptr(local_rp, bounds, detach=False, ctx=ctx)   # C stays alive for two steps
+            bdist.stitch_row_ptr(local_rp, bounds, detach=False, ctx=ctx)   # asynchronous on torch's stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            stitch_done.append(ev)
         return C
+
+    def retire(C):
+        """free a result once the stitch that reads its row_ptr has finished (an event, not timing luck)"""
+        if stitch_done:
+            stitch_done.pop(0).synchronize()
+        C.free()
 
     def fence():
         torch.cuda.synchronize()
@@ -182,48 +265,51 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step().free()
-    bin_ms = None
-    phase_ms = np.zeros(4)
+        retire(step())
     fence()
     t_start = time.perf_counter()
     last = older = None
     for _ in range(args.steps):
-        # two results stay alive: the stitch of step k-1 (asynchronous, torch's stream) may still be
-        # reading C(k-1).row_ptr when step k starts; it has long finished when step k+1 reuses the buffer
+        # two results stay alive: the stitch of step k-1 runs under step k
         if older is not None:
-            older.free()
+            retire(older)
         older = last
         last = step()
-        st = ctx.stats()
-        bin_ms = np.array(st["ms_bin"]) if bin_ms is None else bin_ms + np.array(st["ms_bin"])
-        phase_ms += np.array([st["ms_total"], st["ms_symbolic"], st["ms_numeric"], st["ms_stitch"]])
     fence()
     elapsed = time.perf_counter() - t_start
+    # per-step HIP-event brackets recorded on the library's streams DURING the timed region
+    hist = [ctx.stats(age) for age in range(min(args.steps, MAX_STAT_STEPS))]
+    st = hist[0]
     if older is not None:
-        older.free()
+        retire(older)
+    keys = ("ms_total", "ms_symbolic", "ms_prepass", "ms_count", "ms_numeric", "ms_stitch")
+    phase_ms = {k: float(np.mean([h[k] for h in hist])) for k in keys}
+    bin_ms = np.mean([h["ms_bin"] for h in hist], axis=0)
+    bin_count_ms = np.mean([h["ms_bin_count"] for h in hist], axis=0)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([last.nnz, st["products"], st["bytes_alg"]], dtype=torch.int64, device=dev)
+        tot = torch.tensor([last.nnz, st["products"], st["bytes_alg"], st["bytes_read_alg"]], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        nnz_total, products_total, bytes_total = (int(x) for x in tot.tolist())
+        nnz_total, products_total, bytes_total, read_total = (int(x) for x in tot.tolist())
     else:
-        nnz_total, products_total, bytes_total = int(last.nnz), int(st["products"]), int(st["bytes_alg"])
-    bin_ms /= args.steps
-    phase_ms /= args.steps
+        nnz_total, products_total, bytes_total, read_total = (int(last.nnz), int(st["products"]), int(st["bytes_alg"]),
+                                                              int(st["bytes_read_alg"]))
+    ms_per_step = elapsed / args.steps * 1e3
 
+    prof, prof_path = pmc_profile(wname, world)
     try:
         # ---- roofline of the dominant kernel (this rank's launches) -------------------------
-        # The dominant kernel is k_wave_rows (csrc/wave_rows.inc): ONE kernel source, launched as one
-        # template instance per capacity class (16 of them), back to back on two streams so that one
-        # instance's tail overlaps the next one's ramp-up.  Its "launch" is therefore the whole family:
-        # algorithmic bytes of all one-wave rows (4 B/product + 4 B/output nonzero +
-        # 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start to the
-        # last one's end on the multiply's stream (bspgemm_stats.ms_numeric, which also holds the few
-        # heavy rows of k_dense_rows and the count scan: conservative).  Per-instance event brackets are
-        # listed next to it; they overlap pairwise, so their sum exceeds the family's time.
+        # The dominant kernel is k_wave_rows (csrc/wave_rows.inc), the numeric pass: ONE kernel source,
+        # launched as one template instance per capacity class (16 of them), back to back on two
+        # streams so that one instance's tail overlaps the next one's ramp-up.  Its "launch" is the
+        # whole family: algorithmic bytes of all one-wave rows (4 B/product + 4 B/output
+        # nonzero + 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start
+        # to the last one's end on the multiply's stream (bspgemm_stats.ms_numeric).  Per-instance
+        # event brackets are listed next to it; they overlap pairwise, so their sum exceeds the
+        # family's time.  `symbolic` prices the count kernels (k_wave_count family) the same way with
+        # what they move: 4 B/product + 8 B/A-nonzero + 4 B/row.
         crp, _ = last.download(col_idx=False)
         F_row = np.diff(prefix)[r0:r1]
         a_row = np.diff(rp.astype(np.int64))[r0:r1]
@@ -231,66 +317,72 @@ def main():
         caps = st["bin_cap"]
         DENSE_BIN = len(caps) - 1
         bins = bin_of(F_row, caps)
-        tiles = max(int(st.get("tiles", 1)), 1)            # each class is launched once per row super-tile
         levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
         if levels == 4 and n <= (512 << 15):
             levels = 3                                                           # ... wave_levels_for_cols
         wave = (bins >= 1) & (bins < DENSE_BIN)
-        bytes_wave = int(4 * F_row[wave].sum() + 4 * c_row[wave].sum() + 12 * a_row[wave].sum() + 12 * wave.sum())
-        ms_wave = float(phase_ms[2])
+        read_wave = int(4 * F_row[wave].sum() + 12 * a_row[wave].sum() + 4 * wave.sum())
+        bytes_wave = read_wave + int(4 * c_row[wave].sum() + 8 * wave.sum())
+        ms_wave = phase_ms["ms_numeric"]
         achieved = bytes_wave / (ms_wave * 1e-3) / 1e9 if ms_wave > 0 else 0.0
         instances = []
         for b in range(1, DENSE_BIN):
             selb = bins == b
             if selb.any():
                 by = int(4 * F_row[selb].sum() + 4 * c_row[selb].sum() + 12 * a_row[selb].sum() + 12 * selb.sum())
-                ms_b = float(bin_ms[b]) / tiles
+                ms_b = float(bin_ms[b])
                 instances.append({"chunks": caps[b] // 64, "rows": int(selb.sum()), "products": int(F_row[selb].sum()),
                                   "bytes": by, "ms": round(ms_b, 4),          # ms: event bracket = rocprofv3 average
+                                  "count_ms": round(float(bin_count_ms[b]), 4),
                                   "GBps_while_sharing_the_gpu": round(by / (ms_b * 1e-3) / 1e9, 1) if ms_b > 0 else 0.0})
-        # HBM traffic: PMC counters cannot be read from inside the process, so the committed
-        # rocprofv3 --pmc result of this very command is quoted when the workload is the profiled one
-        # (tools/pmc_run.sh -> profiles/*_pmc_traffic.json: FETCH_SIZE + WRITE_SIZE summed over the
-        # family's instances); otherwise null.
         traffic, traffic_src = None, None
-        try:
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-                prof = json.load(open(path))
-                fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
-                if prof.get("workload") == wname and world == 1 and tiles == 1 and len(fam) == len(instances):
-                    traffic = int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))
-                    traffic_src = os.path.relpath(path, ROOT) + " (FETCH_SIZE+WRITE_SIZE of the %d instances, uncorrected)" % len(fam)
-                    break
-        except Exception:
-            traffic = None
+        if prof:
+            fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
+            if len(fam) == len(instances):
+                # FETCH_SIZE under-counts wide coalesced reads 2x on gfx950 (MI355X_MICROARCH.md, HBM): the
+                # gathers of this kernel are 4-byte accesses, so the raw figure is quoted, uncorrected
+                traffic = int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))
+                traffic_src = prof_path + " (FETCH_SIZE+WRITE_SIZE of the %d instances, uncorrected)" % len(fam)
+        sym_bytes = int(4 * F_row[wave].sum() + 8 * a_row[wave].sum() + 4 * wave.sum())
+        ms_cnt = phase_ms["ms_count"]
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "k_wave_rows<LEVELS=%d,*> (%d capacity-class instances, two streams)" % (levels, len(instances)),
+                    "kernel": "k_wave_rows<LEVELS=%d,*> (numeric pass: %d capacity-class instances, two streams)" % (levels, len(instances)),
                     "bytes_per_launch": bytes_wave, "ms_per_launch": round(ms_wave, 4),
+                    "read_bytes": read_wave,
+                    "read_frac": round(read_wave / (ms_wave * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_wave > 0 else None,
                     "launch_rows": int(wave.sum()), "launch_products": int(F_row[wave].sum()),
-                    "instances": instances}
-
+                    "steps_averaged": len(hist), "instances": instances,
+                    "symbolic": {"kernel": "k_wave_count<*> (symbolic pass: exact row sizes, hash set in LDS)",
+                                 "bytes_per_launch": sym_bytes, "ms_per_launch": round(ms_cnt, 4),
+                                 "achieved": round(sym_bytes / (ms_cnt * 1e-3) / 1e9, 1) if ms_cnt > 0 else None,
+                                 "frac": round(sym_bytes / (ms_cnt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_cnt > 0 else None}}
     except Exception as e:   # the roofline is a reported extra: never lose the metric line to it
         roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
                     "traffic": None, "error": "%s: %s" % (type(e).__name__, e)}
-        caps = list(st.get("bin_cap", []))
-    ms_per_step = elapsed / args.steps * 1e3
     value = nnz_total * args.steps / elapsed / 1e9
+    step_traffic = prof.get("step_total_bytes") if prof else None
     out = {
         "metric": "output nnz/sec (GNZ/s)", "value": round(value, 4), "unit": "GNZ/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": wname, "n": int(n), "nnz_a": int(rp[-1]), "products": products_total,
                    "nnz_c": nnz_total, "parallelism": "row-shards x%d cut at equal work, B replicated" % world,
                    "shard_rows": [int(b) for b in bounds.tolist()]},
         "roofline": roofline,
-        "whole_job": {"bytes_alg": bytes_total, "alg_GBps": round(bytes_total / (ms_per_step * 1e-3) / 1e9, 1),
+        "whole_job": {"bytes_alg": bytes_total, "bytes_read_alg": read_total,
+                      "alg_GBps": round(bytes_total / (ms_per_step * 1e-3) / 1e9, 1),
                       "alg_frac_of_hbm_peak": round(bytes_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS / world, 4),
-                      "rank0_ms": {"total": round(float(phase_ms[0]), 4), "symbolic": round(float(phase_ms[1]), 4),
-                                   "numeric": round(float(phase_ms[2]), 4), "stitch": round(float(phase_ms[3]), 4)},
+                      "read_frac_of_hbm_peak": round(read_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS / world, 4),
+                      "pmc_step_traffic_bytes": step_traffic,
+                      "traffic_ratio": round(step_traffic / bytes_total, 3) if step_traffic else None,
+                      "traffic_source": prof_path if step_traffic else None,
+                      "rank0_ms": {"total": round(phase_ms["ms_total"], 4), "symbolic": round(phase_ms["ms_symbolic"], 4),
+                                   "prepass": round(phase_ms["ms_prepass"], 4), "count": round(phase_ms["ms_count"], 4),
+                                   "numeric": round(phase_ms["ms_numeric"], 4), "stitch": round(phase_ms["ms_stitch"], 4)},
                       "rank0_ms_per_bin": [round(float(x), 4) for x in bin_ms],
+                      "rank0_count_ms_per_bin": [round(float(x), 4) for x in bin_count_ms],
                       "rank0_rows_per_bin": [int(x) for x in st["rows_per_bin"]],
                       "bin_cap": [int(x) for x in st["bin_cap"]]},
     }

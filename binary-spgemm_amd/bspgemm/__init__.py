@@ -34,7 +34,7 @@ _I32P = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _I64P = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 
 STATUS = {0: "OK", 1: "ERR_INVALID", 2: "ERR_ALLOC", 3: "ERR_HIP", 4: "ERR_NO_DEVICE",
-          5: "ERR_OVERFLOW", 6: "ERR_IO", 7: "ERR_FORMAT", 8: "ERR_COMM"}
+          5: "ERR_OVERFLOW", 6: "ERR_IO", 7: "ERR_FORMAT", 8: "ERR_COMM", 9: "ERR_SIZE"}
 
 # every symbol include/bspgemm.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -49,6 +49,8 @@ EXPORTS = [
     "bspgemm_readCOO", "bspgemm_write_mtx", "bspgemm_write_result_mtx", "bspgemm_csr_equal",
     "bspgemm_csr_equal64", "bspgemm_gen_uniform", "bspgemm_gen_rmat", "bspgemm_gen_powerlaw",
     "bspgemm_matrix_from_result", "bspgemm_closure",
+    "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
+    "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
 ]
 
 
@@ -64,17 +66,28 @@ MAX_BINS = 20      # BSPGEMM_MAX_BINS
 
 class Stats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("nnz_a", C.c_int64), ("products", C.c_int64), ("nnz_c", C.c_int64),
-                ("bytes_alg", C.c_int64), ("rows_per_bin", C.c_int64 * MAX_BINS), ("ms_total", C.c_float),
-                ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_stitch", C.c_float),
-                ("ms_bin", C.c_float * MAX_BINS), ("tiles", C.c_int), ("bins", C.c_int),
+                ("bytes_alg", C.c_int64), ("bytes_read_alg", C.c_int64), ("rows_per_bin", C.c_int64 * MAX_BINS),
+                ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_prepass", C.c_float),
+                ("ms_count", C.c_float), ("ms_numeric", C.c_float), ("ms_stitch", C.c_float),
+                ("ms_bin", C.c_float * MAX_BINS), ("ms_bin_count", C.c_float * MAX_BINS),
+                ("t_bin", C.c_float * MAX_BINS), ("t_bin_count", C.c_float * MAX_BINS), ("bins", C.c_int),
                 ("bin_cap", C.c_int * MAX_BINS)]
 
     def as_dict(self):
-        arrays = ("rows_per_bin", "ms_bin", "bin_cap")
+        arrays = ("rows_per_bin", "ms_bin", "ms_bin_count", "t_bin", "t_bin_count", "bin_cap")
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in arrays}
         for k in arrays:
             d[k] = list(getattr(self, k))[: self.bins]
         return d
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+GATHERV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t), C.c_int)
+
+
+class HostTransport(C.Structure):
+    """bspgemm_host_transport: all-gather / gatherv callbacks on host buffers"""
+    _fields_ = [("user", C.c_void_p), ("allgather", ALLGATHER_FN), ("gatherv", GATHERV_FN)]
 
 
 def build():
@@ -85,6 +98,29 @@ def build():
 _lib = None
 
 
+def hip_runtimes():
+    """paths of the libamdhip64 copies mapped into this process (there must be exactly one)"""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+def check_single_hip_runtime():
+    """Two HIP runtimes in one process (torch's bundled libamdhip64 + /opt/rocm's, which
+    libbspgemm.so finds through its rpath when it is loaded BEFORE torch) each keep their own
+    device state: handles of one are garbage to the other and the process segfaults on the first
+    cross call (seen in round 1 as a crash in the RCCL stitch test).  Load order decides: whoever
+    is first wins the soname.  Fail loudly instead of crashing later."""
+    libs = hip_runtimes()
+    if len(libs) > 1:
+        raise RuntimeError("two HIP runtimes are mapped into this process: %s -- import torch BEFORE "
+                           "loading libbspgemm.so (bspgemm.lib() does that itself), or do not import "
+                           "torch at all" % libs)
+    return libs
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -92,11 +128,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError("%s is not built: run `make -C binary-spgemm_amd` "
                                 "(or __graft_entry__.build())" % LIB_PATH)
-    try:   # a process that also uses torch must load torch's bundled HIP runtime first (one runtime only)
-        import torch  # noqa: F401
-    except Exception:
-        pass
+    # a process that also uses torch must load torch's bundled HIP runtime first (one runtime only);
+    # where torch is not installed at all the library simply uses /opt/rocm's
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401  (a broken torch install raises here: loudly, not a later segfault)
     L = C.CDLL(LIB_PATH)
+    check_single_hip_runtime()
     VP, PVP = C.c_void_p, C.POINTER(C.c_void_p)
     L.bspgemm_status_string.restype = C.c_char_p
     L.bspgemm_status_string.argtypes = [C.c_int]
@@ -131,6 +169,7 @@ def lib():
     L.bspgemm_row_work_prefix.argtypes = [VP, VP, VP, _I64P]
     L.bspgemm_partition_rows.argtypes = [VP, VP, VP, C.c_int, _I32P]
     L.bspgemm_last_stats.argtypes = [VP, C.POINTER(Stats)]
+    L.bspgemm_stats_at.argtypes = [VP, C.c_int, C.POINTER(Stats)]
     IPP = C.POINTER(C.POINTER(C.c_int))
     L.SpGEMM_hip.argtypes = [_I32P, VP, C.c_int, _I32P, _I32P, C.c_int, IPP, _I32P, C.c_int]
     L.SpGEMM_hip_bigslice.argtypes = [_I32P, _I32P, C.c_int, _I32P, _I32P, C.c_int, IPP, _I32P,
@@ -148,6 +187,13 @@ def lib():
     U32PP = C.POINTER(C.POINTER(C.c_uint32))
     L.bspgemm_readCOO.argtypes = [C.c_char_p, U32PP, U32PP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_uint32)]
+    L.bspgemm_readCOO_ex.argtypes = [C.c_char_p, C.c_uint, U32PP, U32PP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint32)]
+    L.bspgemm_comm_create_host.argtypes = [VP, C.POINTER(HostTransport), C.c_int, C.c_int, PVP]
+    L.bspgemm_comm_rank.argtypes = [VP]
+    L.bspgemm_comm_size.argtypes = [VP]
+    L.bspgemm_comm_gather_col_idx.argtypes = [VP, VP, _I64P, C.c_int, VP]
+    L.SpGEMM_hip_multi.argtypes = [VP, _I32P, _I32P, C.c_int, _I32P, _I32P, C.c_int, IPP, _I32P, C.c_int]
     L.bspgemm_write_mtx.argtypes = [C.c_char_p, C.c_int, C.c_int, _I32P, _I32P]
     L.bspgemm_write_result_mtx.argtypes = [C.c_char_p, C.c_int, C.c_int, _I64P, _I32P]
     L.bspgemm_csr_equal.argtypes = [_I32P, _I32P, _I32P, _I32P, C.c_int]
@@ -179,13 +225,22 @@ def _i32(a):
 
 
 # ------------------------------------------------------------------ host utilities --------
-def readCOO(path):
-    """bspgemm_readCOO: (row_ptr int32[M+1], col_idx int32[nnz], M, N); CSR of the transposed file."""
+READ_EXPAND_SYMMETRIC = 1
+
+
+def readCOO(path, expand_symmetric=False):
+    """bspgemm_readCOO: (row_ptr int32[M+1], col_idx int32[nnz], M, N); CSR of the transposed file.
+    expand_symmetric=True: bspgemm_readCOO_ex with BSPGEMM_READ_EXPAND_SYMMETRIC (opt-in, not the
+    reference's behaviour)."""
     L = lib()
     rp, ci = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
     m, n, nz = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    _chk(L.bspgemm_readCOO(os.fsencode(path), C.byref(rp), C.byref(ci), C.byref(m), C.byref(n), C.byref(nz)),
-         "readCOO(%s)" % path)
+    if expand_symmetric:
+        st = L.bspgemm_readCOO_ex(os.fsencode(path), READ_EXPAND_SYMMETRIC, C.byref(rp), C.byref(ci), C.byref(m),
+                                  C.byref(n), C.byref(nz))
+    else:
+        st = L.bspgemm_readCOO(os.fsencode(path), C.byref(rp), C.byref(ci), C.byref(m), C.byref(n), C.byref(nz))
+    _chk(st, "readCOO(%s)" % path)
     # the CSR has one row per FILE COLUMN (N); the reference only ever reads square files (n = M)
     return _take_i32(rp, n.value + 1), _take_i32(ci, nz.value), m.value, n.value
 
@@ -238,7 +293,9 @@ class Context:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
-        _chk(lib().bspgemm_create(device, C.byref(self._h)), "bspgemm_create")
+        L = lib()
+        check_single_hip_runtime()
+        _chk(L.bspgemm_create(device, C.byref(self._h)), "bspgemm_create")
         self.device = device
         self._children = weakref.WeakSet()      # matrices/results must go before their context
 
@@ -307,9 +364,10 @@ class Context:
         _chk(lib().bspgemm_lengths_to_row_ptr(self._h, C.c_void_p(int(d_lengths)), int(world), int(width), b,
                                               C.c_void_p(int(d_row_ptr)), C.c_void_p(hip_stream or 0)), "lengths_to_row_ptr")
 
-    def stats(self):
+    def stats(self, age=0):
+        """counters and HIP-event times of the last multiply (age 0) or of an earlier one (age <= 15)"""
         s = Stats()
-        _chk(lib().bspgemm_last_stats(self._h, C.byref(s)), "last_stats")
+        _chk(lib().bspgemm_stats_at(self._h, age, C.byref(s)), "stats_at")
         return s.as_dict()
 
     def row_work_prefix(self, A, B):

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <chrono>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <mutex>
 #include <new>
 
@@ -34,6 +35,16 @@ static bspgemm_status fail(bspgemm_status st, const char *what, const char *file
             snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
                      __FILE__, __LINE__);                                                  \
             return (e_ == hipErrorOutOfMemory) ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP;      \
+        }                                                                                  \
+    } while (0)
+// the same with a clean-up: `bail(status)` must be in scope (frees what the function has built so far)
+#define HIPCHK_B(call)                                                                     \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                     __FILE__, __LINE__);                                                  \
+            return bail((e_ == hipErrorOutOfMemory) ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP);\
         }                                                                                  \
     } while (0)
 #define NCCLCHK(call)                                                                      \
@@ -58,22 +69,21 @@ extern "C" const char *bspgemm_status_string(bspgemm_status s)
     case BSPGEMM_ERR_NO_DEVICE: return "no gfx950 device (this library has no CPU fallback)";
     case BSPGEMM_ERR_OVERFLOW: return "result exceeds the int32 drop-in interface";
     case BSPGEMM_ERR_IO: return "file I/O error";
-    case BSPGEMM_ERR_FORMAT: return "Matrix Market format rejected";
+    case BSPGEMM_ERR_FORMAT: return "Matrix Market banner rejected";
+    case BSPGEMM_ERR_SIZE: return "Matrix Market size line or entry rejected";
     case BSPGEMM_ERR_COMM: return "RCCL error";
     }
     return "unknown status";
 }
 
 // ------------------------------------------------------------------ objects --------------
-constexpr int kMaxTiles = 16;   // row super-tiles whose compaction overlaps the next tile's accumulate
-
 struct HostScalars {
     long long totalF;
     long long nnzC;
     int bin_count[kNumBins];
     int a_lo, a_hi;
     long long products;                 // true product count of a masked multiply (totalF is the mask total there)
-    long long fb[kMaxTiles + 1];        // Fprefix at the super-tile boundaries
+    long long heavy_total;              // entries the heavy rows may need in the workspace
 };
 
 struct bspgemm_context {
@@ -82,32 +92,42 @@ struct bspgemm_context {
     bool own_stream = false;
     hipStream_t stream_b = nullptr;     // second accumulate stream (capacity classes run concurrently)
     hipStream_t stream_c = nullptr;     // compaction stream
-    hipEvent_t ev_tile[kMaxTiles][3] = {};          // per super-tile: classes on stream_b done / scan done / start fence
-    hipEvent_t ev_cls[kMaxTiles][kNumBins][2] = {}; // per (super-tile, class): launch brackets
+    hipEvent_t ev_tile[2][3] = {};                  // per phase (symbolic count, numeric): fork / joins of the side streams
     hipEvent_t ev_join = nullptr;
+    // timing events and counters of the last kStatSlots multiplies (bspgemm_stats_at): a caller that
+    // times K steps reads K sets of HIP-event brackets afterwards instead of one
+    struct StatSlot {
+        hipEvent_t ev[5] = {};                      // start / classes known / row sizes known / rows emitted / done
+        hipEvent_t ev_cls[2][kNumBins][2] = {};     // per (phase, class): launch brackets
+        int R = 0;
+        HostScalars h = {};
+        long long products = 0, nnz_c = 0;
+        int cls_n[2][kNumBins] = {};
+        bool used = false;
+    };
+    static constexpr int kStatSlots = 16;
+    StatSlot slots[kStatSlots];
+    int slot_head = 0;                              // the most recent multiply's slot
     long long *stitch_partials = nullptr;           // scan scratch of bspgemm_lengths_to_row_ptr
     size_t stitch_partials_cap = 0;
-    int *h_bin_tiles = nullptr;         // pinned copy of bin_tiles
-    size_t h_bin_tiles_cap = 0;
     // per-row workspace (capacity rows_cap rows)
     size_t rows_cap = 0;
     long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr, *Fmask = nullptr;
+    long long *hpartials = nullptr;     // per scan tile: workspace entries of its heavy rows (scanned)
     int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
     RowRec *rec = nullptr;
     // per-A-nonzero workspace: (start,length) of the B row behind every A nonzero
     size_t ab_cap = 0;
     int2 *ab = nullptr;
-    // upper-bound placed rows
+    // upper-bound placed rows: the heavy rows of a plain product, every row of a masked one
     size_t tmp_cap = 0;
     int *tmp = nullptr;
     HostScalars *h = nullptr;          // pinned
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // freed result buffers, reused by the next multiply (results are allocated per call like the
     // reference's per-call malloc of Ccol, final/SpGEMM_mpi_omp.c:115, without paying hipMalloc)
     struct CachedBuf { void *p; size_t bytes; };
     CachedBuf cache[8] = {};
-    bspgemm_stats stats;
-    bool stats_valid = false;
+    size_t cache_budget = 0;            // bytes the cache may pin (a quarter of the device memory)
 };
 
 extern "C" int bspgemm_par_max_plus_one(const int *idx, long long n);              // host/par_copy.c
@@ -136,6 +156,13 @@ static bspgemm_status use_device(bspgemm_context *ctx)
     return BSPGEMM_OK;
 }
 
+extern "C" int bspgemm_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ndev;
+}
+
 extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
 {
     if (!out) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
@@ -159,12 +186,18 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     ctx->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
-    for (auto &e : ctx->ev) HIPCHK(hipEventCreate(&e));
+    for (auto &sl : ctx->slots) {
+        for (auto &e : sl.ev) HIPCHK(hipEventCreate(&e));
+        for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) HIPCHK(hipEventCreate(&e));
+    }
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream_c, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (auto &t : ctx->ev_tile) for (auto &e : t) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &t : ctx->ev_cls) for (auto &c : t) for (auto &e : c) HIPCHK(hipEventCreate(&e));
+    ctx->cache_budget = prop.totalGlobalMem / 4;
+    if (getenv("BSPGEMM_DEBUG_ALLOC"))
+        fprintf(stderr, "[bspgemm] device %d: %s, %zu MiB, %d CUs; result cache budget %zu MiB\n", device,
+                prop.gcnArchName, (size_t)(prop.totalGlobalMem >> 20), prop.multiProcessorCount, ctx->cache_budget >> 20);
     *out = ctx;
     return BSPGEMM_OK;
 }
@@ -176,17 +209,18 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
-    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask);
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
     if (ctx->h) hipHostFree(ctx->h);
-    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    for (auto &sl : ctx->slots) {
+        for (auto &e : sl.ev) if (e) hipEventDestroy(e);
+        for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) if (e) hipEventDestroy(e);
+    }
     for (auto &c : ctx->cache) if (c.p) hipFree(c.p);
     if (ctx->stream_b) { hipStreamSynchronize(ctx->stream_b); hipStreamDestroy(ctx->stream_b); }
     if (ctx->stream_c) { hipStreamSynchronize(ctx->stream_c); hipStreamDestroy(ctx->stream_c); }
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     hipFree(ctx->stitch_partials);
     for (auto &t : ctx->ev_tile) for (auto &e : t) if (e) hipEventDestroy(e);
-    for (auto &t : ctx->ev_cls) for (auto &c : t) for (auto &e : c) if (e) hipEventDestroy(e);
-    if (ctx->h_bin_tiles) hipHostFree(ctx->h_bin_tiles);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -228,14 +262,15 @@ extern "C" bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, 
     if (bspgemm_status st = use_device(ctx)) return st;
     bspgemm_matrix *m = new (std::nothrow) bspgemm_matrix{ctx, rows, cols, nnz, nullptr, nullptr, true};
     if (!m) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
+    auto bail = [&](bspgemm_status st) { bspgemm_matrix_free(m); return st; };   // handle + device arrays
     // +1 int of slack on col_idx so an empty matrix still has a valid pointer
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)rows + 1) * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)nnz + 1) * sizeof(int)));
-    HIPCHK(hipMemcpyAsync(m->d_row_ptr, row_ptr, ((size_t)rows + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)rows + 1) * sizeof(int)));
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)nnz + 1) * sizeof(int)));
+    HIPCHK_B(hipMemcpyAsync(m->d_row_ptr, row_ptr, ((size_t)rows + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     if (nnz > 0)
-        HIPCHK(hipMemcpyAsync(m->d_col_idx, col_idx + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK_B(hipMemcpyAsync(m->d_col_idx, col_idx + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     launch_rebase_i32(m->d_row_ptr, rows + 1, (int)base, ctx->stream);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK_B(hipStreamSynchronize(ctx->stream));
     *out = m;
     return BSPGEMM_OK;
 }
@@ -273,8 +308,8 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     if (rows <= ctx->rows_cap) return BSPGEMM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_tiles);
-    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask);
-    ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = ctx->Fmask = nullptr;
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
+    ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = ctx->Fmask = ctx->hpartials = nullptr;
     ctx->cnt = ctx->bin_tiles = nullptr;
     ctx->rec = nullptr;
     ctx->rows_cap = 0;
@@ -284,11 +319,9 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fmask), cap * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->Fprefix), (cap + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->partials), (tiles + 1) * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hpartials), (tiles + 1) * sizeof(long long)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->cnt), cap * sizeof(int)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
-    if (ctx->h_bin_tiles) hipHostFree(ctx->h_bin_tiles);
-    ctx->h_bin_tiles = nullptr;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_bin_tiles), (tiles + 1) * kNumBins * sizeof(int), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
     ctx->rows_cap = cap;
@@ -322,7 +355,7 @@ static bspgemm_status ensure_tmp(bspgemm_context *ctx, size_t ints)
 }
 
 // result buffers: best fit from the context's cache of freed results, else hipMalloc
-static hipError_t result_alloc(bspgemm_context *ctx, void **out, size_t bytes)
+static int result_cache_find(const bspgemm_context *ctx, size_t bytes)
 {
     int best = -1;
     for (int i = 0; i < 8; i++) {
@@ -331,12 +364,27 @@ static hipError_t result_alloc(bspgemm_context *ctx, void **out, size_t bytes)
             (best < 0 || c.bytes < ctx->cache[best].bytes))
             best = i;
     }
+    return best;
+}
+static bool result_cached(const bspgemm_context *ctx, size_t bytes) { return result_cache_find(ctx, bytes) >= 0; }
+
+static hipError_t result_alloc(bspgemm_context *ctx, void **out, size_t bytes)
+{
+    const int best = result_cache_find(ctx, bytes);
     if (best >= 0) {
         *out = ctx->cache[best].p;
         ctx->cache[best].p = nullptr;
         return hipSuccess;
     }
+    static const bool dbg = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
+    if (dbg) {
+        fprintf(stderr, "[bspgemm] hipMalloc(%zu) %.3f ms; cache:", bytes,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        for (const auto &c : ctx->cache) if (c.p) fprintf(stderr, " %zu", c.bytes);
+        fprintf(stderr, "\n");
+    }
     if (e == hipErrorOutOfMemory) {                     // drop the cache and retry once
         for (auto &c : ctx->cache) if (c.p) { hipFree(c.p); c.p = nullptr; }
         (void)hipGetLastError();
@@ -351,6 +399,23 @@ static size_t result_bytes_colidx(long long nnz) { return ((size_t)nnz + 4) * si
 static void result_release(bspgemm_context *ctx, void *p, size_t bytes)
 {
     if (!p) return;
+    // the cache is capped by BYTES as well as by slots: freed results of a large product must not
+    // pin the memory the next one needs (the smallest buffers go first)
+    static const bool dbg = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
+    size_t held = 0;
+    for (const auto &c : ctx->cache) if (c.p) held += c.bytes;
+    if (dbg && held + bytes > ctx->cache_budget)
+        fprintf(stderr, "[bspgemm] result cache over budget: holds %zu, released %zu, budget %zu\n", held, bytes, ctx->cache_budget);
+    while (held + bytes > ctx->cache_budget && held > 0) {
+        int small = -1;
+        for (int i = 0; i < 8; i++)
+            if (ctx->cache[i].p && (small < 0 || ctx->cache[i].bytes < ctx->cache[small].bytes)) small = i;
+        if (small < 0) break;
+        held -= ctx->cache[small].bytes;
+        hipFree(ctx->cache[small].p);
+        ctx->cache[small].p = nullptr;
+    }
+    if (bytes > ctx->cache_budget) { hipFree(p); return; }
     int slot = -1;
     for (int i = 0; i < 8; i++)
         if (!ctx->cache[i].p) { slot = i; break; }
@@ -376,180 +441,296 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
     return BSPGEMM_OK;
 }
 
-static bspgemm_status multiply_impl(bspgemm_context *ctx, const bspgemm_matrix *A,
-                                    const bspgemm_matrix *B, const bspgemm_matrix *Fm,
-                                    int row_begin, int row_end, bspgemm_result **out)
+static int class_streams_from_env()
+{
+    int n = 2;                                         // measured: 2 -8 % accumulate time, 3 no better
+    if (const char *e = getenv("BSPGEMM_CLASS_STREAMS")) n = atoi(e);
+    return n < 1 ? 1 : (n > 3 ? 3 : n);
+}
+
+// class launch order of a phase: the heavy rows first (few long-running workgroups: started early
+// they finish under the other classes instead of being the phase's tail), then the one-wave
+// classes by capacity
+static inline int class_at(int pos) { return pos == 1 ? kDenseBin : pos - 1; }
+
+// closes the multiply's stat slot (its events have all completed: the caller has synchronised)
+static void close_slot(bspgemm_context *ctx, int R, const HostScalars *h, long long products, long long nnz_c,
+                       const int (*cls_n)[kNumBins])
+{
+    bspgemm_context::StatSlot &sl = ctx->slots[ctx->slot_head];
+    sl.R = R;
+    sl.h = *h;
+    sl.products = products;
+    sl.nnz_c = nnz_c;
+    memcpy(sl.cls_n, cls_n, sizeof sl.cls_n);
+    sl.used = true;
+}
+
+static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
+{
+    memset(&st, 0, sizeof st);
+    const int R = sl.R;
+    st.rows = R;
+    st.nnz_a = R > 0 ? (long long)sl.h.a_hi - sl.h.a_lo : 0;
+    st.products = sl.products;
+    st.nnz_c = sl.nnz_c;
+    st.bytes_alg = 4ll * (R + 1) + 12ll * st.nnz_a + 4ll * st.products + 4ll * sl.nnz_c + 8ll * (R + 1);
+    st.bytes_read_alg = st.bytes_alg - 4ll * sl.nnz_c - 8ll * (R + 1);
+    static_assert(kMaxBins == BSPGEMM_MAX_BINS && kNumBins <= kMaxBins, "stats arrays hold every class");
+    st.bins = kNumBins;
+    for (int b = 0; b < kNumBins; b++) {
+        st.rows_per_bin[b] = sl.h.bin_count[b];
+        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : 64 * kWaveChunks[b]);
+    }
+    hipEventElapsedTime(&st.ms_total, sl.ev[0], sl.ev[4]);
+    hipEventElapsedTime(&st.ms_prepass, sl.ev[0], sl.ev[1]);
+    hipEventElapsedTime(&st.ms_count, sl.ev[1], sl.ev[2]);
+    hipEventElapsedTime(&st.ms_symbolic, sl.ev[0], sl.ev[2]);
+    hipEventElapsedTime(&st.ms_numeric, sl.ev[2], sl.ev[3]);
+    hipEventElapsedTime(&st.ms_stitch, sl.ev[3], sl.ev[4]);
+    for (int ph = 0; ph < 2; ph++)
+        for (int b = 1; b < kNumBins; b++)
+            if (sl.cls_n[ph][b] > 0) {
+                float ms = 0, t0 = 0;
+                hipEventElapsedTime(&ms, sl.ev_cls[ph][b][0], sl.ev_cls[ph][b][1]);
+                hipEventElapsedTime(&t0, sl.ev[0], sl.ev_cls[ph][b][0]);
+                (ph == 0 ? st.ms_bin_count : st.ms_bin)[b] = ms;
+                (ph == 0 ? st.t_bin_count : st.t_bin)[b] = t0;
+            }
+}
+
+// C rows [row_begin,row_end) of A*B:  symbolic (row work -> classes -> EXACT row sizes -> scan =
+// C.row_ptr) then numeric (every one-wave row emitted at its final place in a C.col_idx of exactly
+// nnz(C) entries) -- the two passes BASELINE.json's north star names.  Heavy rows (F_i > 2048) are
+// accumulated and read out once, during the symbolic phase, into a workspace bounded by
+// sum(min(F_i, cols)), and moved to their place during the numeric phase.
+static bspgemm_status multiply_plain(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                     int row_begin, int row_end, bspgemm_result **out)
 {
     if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
     *out = nullptr;
     if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
-    if (Fm && (Fm->ctx != ctx || Fm->rows < row_end)) return FAIL(BSPGEMM_ERR_INVALID, "mask has fewer rows than A / wrong context");
     if (bspgemm_status st = use_device(ctx)) return st;
     const int R = row_end - row_begin;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->stream, sB = ctx->stream_b, sC = ctx->stream_c;
     if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
     if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
 
     bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
     if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
     auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
-#define HIPCHK_C(call)                                                                      \
-    do {                                                                                   \
-        hipError_t e_ = (call);                                                            \
-        if (e_ != hipSuccess) {                                                            \
-            snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),  \
-                     __FILE__, __LINE__);                                                  \
-            return bail((e_ == hipErrorOutOfMemory) ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP);\
-        }                                                                                  \
-    } while (0)
+    ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
+    bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
+    slot.used = false;
 
-    hipStream_t sB = ctx->stream_b, sC = ctx->stream_c;
-    HIPCHK_C(hipEventRecord(ctx->ev[0], s));
-    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
+    HIPCHK_B(hipEventRecord(slot.ev[0], s));
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
 
-    // Row super-tiles (multiples of the 2048-row scan tile).  Tile k's rows are accumulated, their
-    // counts scanned, and their compaction runs on its own stream while tile k+1 is accumulated.
+    // ---- symbolic 1: per-row products, their prefix, capacity classes ---------------------
     const int scan_tiles = (R + 2047) / 2048;
-    int T = 1;                                         // BSPGEMM_TILES > 1 turns the pipelining on
-    if (const char *e = getenv("BSPGEMM_TILES")) T = atoi(e);
-    if (T < 1) T = 1;
-    if (T > kMaxTiles) T = kMaxTiles;
-    if (R < (1 << 18)) T = 1;
-    if (T > scan_tiles && scan_tiles > 0) T = scan_tiles;
-    int tb[kMaxTiles + 1];
-    for (int k = 0; k <= T; k++) {
-        long long t = (long long)scan_tiles * k / T * 2048;
-        tb[k] = (k == T || t > R) ? R : (int)t;
-    }
-    auto tile_index = [&](int row) { return row >= R ? scan_tiles : row / 2048; };
-
-    // ---- symbolic: per-row products, their prefix, capacity classes ---------------------
+    const int heavy_cols = B->cols > 0 ? B->cols : 1;
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
+    launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, s);
     HostScalars *h = ctx->h;
-    h->products = -1;
-    const long long *size_by = ctx->F;          // what rows are binned and offset by: products ...
-    if (Fm) {                                   // ... or, masked, the mask row's length (|C_i| <= |F_i|)
-        launch_sum_i64(ctx->F, R, ctx->partials, s);
-        HIPCHK_C(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
-                                hipMemcpyDeviceToHost, s));
-        launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
-        size_by = ctx->Fmask;
-    }
-    launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, s);
-    HIPCHK_C(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIPCHK_C(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK_C(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK_C(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (R > 0) {
-        HIPCHK_C(hipMemcpyAsync(ctx->h_bin_tiles, ctx->bin_tiles, ((size_t)scan_tiles + 1) * kNumBins * sizeof(int),
-                                hipMemcpyDeviceToHost, s));
-        for (int k = 0; k <= T; k++)
-            HIPCHK_C(hipMemcpyAsync(&h->fb[k], ctx->Fprefix + tb[k], sizeof(long long), hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK_C(hipEventRecord(ctx->ev[1], s));
-    HIPCHK_C(hipStreamSynchronize(s));
+    HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->heavy_total, ctx->hpartials + scan_tiles, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[1], s));
+    HIPCHK_B(hipStreamSynchronize(s));
     const long long totalF = R > 0 ? h->totalF : 0;
-    if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
-    if (bspgemm_status st = ensure_tmp(ctx, (size_t)totalF + 1)) return bail(st);
-    // C.col_idx is taken with the upper-bound size F (known now) so that no size read-back sits
-    // between the accumulate and the compaction of a tile; nnz(C) <= F entries of it are used
-    HIPCHK_C(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(totalF)));
-    C->col_cap = totalF;
+    if (R == 0) { memset(h->bin_count, 0, sizeof h->bin_count); h->heavy_total = 0; }
+    if (bspgemm_status st = ensure_tmp(ctx, (size_t)h->heavy_total + 1)) return bail(st);
 
-    // ---- numeric + stitch, pipelined over the super-tiles --------------------------------
-    const int levels = wave_levels_for_cols(B->cols);
     size_t bin_start[kNumBins + 1] = {0, 0};               // class b's segment of rec[] (class 0 has none)
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
-    int cls_n[kMaxTiles][kNumBins] = {};
-    // The class launches of a tile are independent (disjoint rows of tmp and cnt): they are spread
-    // round-robin over two (at most three) streams so that one launch's draining tail overlaps the next
-    // launch's ramp-up.  With super-tiles, stream_c is busy compacting the previous tile.
-    int class_streams = 2;                             // measured: 2 -8 % numeric time, 3 no better
-    if (const char *e = getenv("BSPGEMM_CLASS_STREAMS")) class_streams = atoi(e);
+    int cls_n[2][kNumBins] = {};
     hipStream_t lanes[3] = {s, sB, sC};
-    const int nlanes = T > 1 ? 2 : (class_streams < 1 ? 1 : (class_streams > 3 ? 3 : class_streams));
-    for (int k = 0; k < T && R > 0; k++) {
-        const int *bt0 = ctx->h_bin_tiles + (size_t)tile_index(tb[k]) * kNumBins;
-        const int *bt1 = ctx->h_bin_tiles + (size_t)tile_index(tb[k + 1]) * kNumBins;
+    const int nlanes = class_streams_from_env();
+    // The class launches of a phase are independent (disjoint rows): they alternate over two streams
+    // so that one launch's draining tail overlaps the next one's ramp-up.  The side streams start
+    // behind the phase's inputs (fork) and the main stream waits for them at its end (join).
+    auto fork = [&](hipEvent_t ev) -> hipError_t {
+        if (hipError_t e = hipEventRecord(ev, s)) return e;
+        for (int l = 1; l < 3; l++)
+            if (hipError_t e = hipStreamWaitEvent(lanes[l], ev, 0)) return e;
+        return hipSuccess;
+    };
+    auto join = [&](int l, hipEvent_t ev) -> hipError_t {
+        if (hipError_t e = hipEventRecord(ev, lanes[l])) return e;
+        return hipStreamWaitEvent(s, ev, 0);
+    };
+
+    // ---- symbolic 2: exact |C_i| of every row, scanned into C.row_ptr -----------------------
+    if (R > 0) {
+        HIPCHK_B(fork(ctx->ev_tile[0][0]));
         for (int pos = 1; pos < kNumBins; pos++) {
-            // launch order: the heavy rows first (few long-running workgroups: started early they
-            // finish under the other classes instead of being the multiply's tail), then the
-            // one-wave classes by capacity
-            const int b = pos == 1 ? kDenseBin : pos - 1;
-            const int n = bt1[b] - bt0[b];
-            cls_n[k][b] = n;
+            const int b = class_at(pos);
+            const int n = h->bin_count[b];
+            cls_n[0][b] = n;
             if (n <= 0) continue;
             hipStream_t sx = lanes[pos % nlanes];
-            const RowRec *rec = ctx->rec + bin_start[b] + bt0[b];
-            const long long *recpre = ctx->recpre + bin_start[b] + bt0[b];
-            HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][0], sx));
-            if (Fm && b <= kWaveBins && wave_masked_supported(B->cols))
+            const RowRec *rec = ctx->rec + bin_start[b];
+            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
+            if (b <= kWaveBins)
+                launch_wave_count(b, ctx->ab, B->d_col_idx, B->cols, rec, n, row_begin, ctx->cnt, sx);
+            else
+                HIPCHK_B(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
+                                           row_begin, ctx->tmp, ctx->cnt, sx));
+            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
+        }
+        HIPCHK_B(hipGetLastError());
+        for (int l = 1; l < nlanes; l++) HIPCHK_B(join(l, ctx->ev_tile[0][l]));
+        launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, nullptr, s);
+    } else {
+        HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
+    }
+    HIPCHK_B(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[2], s));
+
+    // C.col_idx: nnz(C) <= F entries are needed.  A cached buffer that holds F entries is taken
+    // without waiting for nnz(C); otherwise the size is read back and exactly that is allocated
+    // (F itself when it is within 2 % of nnz(C): the next product of this shape then finds it cached).
+    bool synced = false;
+    if (result_cached(ctx, result_bytes_colidx(totalF))) {
+        HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(totalF)));
+        C->col_cap = totalF;
+    } else {
+        HIPCHK_B(hipStreamSynchronize(s));
+        synced = true;
+        const long long want = (totalF - h->nnzC <= h->nnzC / 50 + 4096) ? totalF : h->nnzC;
+        HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(want)));
+        C->col_cap = want;
+    }
+
+    // ---- numeric: every row emitted at its final place ------------------------------------------
+    if (R > 0) {
+        const int levels = wave_levels_for_cols(B->cols);
+        HIPCHK_B(fork(ctx->ev_tile[1][0]));
+        for (int pos = 1; pos < kNumBins; pos++) {
+            const int b = class_at(pos);
+            const int n = h->bin_count[b];
+            cls_n[1][b] = n;
+            if (n <= 0) continue;
+            const RowRec *rec = ctx->rec + bin_start[b];
+            const long long *recpre = ctx->recpre + bin_start[b];
+            // the heavy rows' move runs beside the class launches on the third stream
+            hipStream_t sx = b == kDenseBin ? sC : lanes[pos % nlanes];
+            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
+            if (b <= kWaveBins)
+                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
+                                 C->d_col_idx, nullptr, sx);
+            else
+                launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
+            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
+        }
+        HIPCHK_B(hipGetLastError());
+        for (int l = 1; l < nlanes; l++) HIPCHK_B(join(l, ctx->ev_tile[1][l]));
+    }
+    HIPCHK_B(hipEventRecord(slot.ev[3], s));
+    if (R > 0) HIPCHK_B(join(2, ctx->ev_join));            // the heavy rows' move (third stream)
+    HIPCHK_B(hipEventRecord(slot.ev[4], s));
+    HIPCHK_B(hipStreamSynchronize(s));
+    (void)synced;
+    C->nnz = h->nnzC;
+    close_slot(ctx, R, h, totalF, C->nnz, cls_n);
+    *out = C;
+    return BSPGEMM_OK;
+}
+
+// C = F .* (A*B).  The mask bounds a row (|C_i| <= |F_i|), usually far below its product count, so
+// rows are binned and placed by MASK length in an upper-bound workspace and squeezed together by
+// the compaction kernel once the counts are scanned.
+static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_matrix *A,
+                                           const bspgemm_matrix *B, const bspgemm_matrix *Fm,
+                                           int row_begin, int row_end, bspgemm_result **out)
+{
+    if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
+    *out = nullptr;
+    if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
+    if (Fm->ctx != ctx || Fm->rows < row_end) return FAIL(BSPGEMM_ERR_INVALID, "mask has fewer rows than A / wrong context");
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int R = row_end - row_begin;
+    hipStream_t s = ctx->stream, sB = ctx->stream_b, sC = ctx->stream_c;
+    if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+    if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
+
+    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
+    if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
+    auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
+    ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
+    bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
+    slot.used = false;
+
+    HIPCHK_B(hipEventRecord(slot.ev[0], s));
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
+    HostScalars *h = ctx->h;
+    h->products = 0;
+    launch_sum_i64(ctx->F, R, ctx->partials, s);
+    HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
+                            hipMemcpyDeviceToHost, s));
+    launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
+    launch_scan_and_bin(ctx->Fmask, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, s);
+    HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[1], s));
+    HIPCHK_B(hipEventRecord(slot.ev[2], s));               // no separate count phase here
+    HIPCHK_B(hipStreamSynchronize(s));
+    const long long total = R > 0 ? h->totalF : 0;         // sum of the mask-row lengths: bounds nnz(C)
+    if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
+    if (bspgemm_status st = ensure_tmp(ctx, (size_t)total + 1)) return bail(st);
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(total)));
+    C->col_cap = total;
+
+    size_t bin_start[kNumBins + 1] = {0, 0};
+    for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
+    int cls_n[2][kNumBins] = {};
+    hipStream_t lanes[3] = {s, sB, sC};
+    const int nlanes = class_streams_from_env();
+    if (R > 0) {
+        HIPCHK_B(hipEventRecord(ctx->ev_tile[0][0], s));
+        for (int l = 1; l < nlanes; l++) HIPCHK_B(hipStreamWaitEvent(lanes[l], ctx->ev_tile[0][0], 0));
+        for (int pos = 1; pos < kNumBins; pos++) {
+            const int b = class_at(pos);
+            const int n = h->bin_count[b];
+            cls_n[1][b] = n;
+            if (n <= 0) continue;
+            hipStream_t sx = lanes[pos % nlanes];
+            const RowRec *rec = ctx->rec + bin_start[b];
+            const long long *recpre = ctx->recpre + bin_start[b];
+            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
+            if (b <= kWaveBins && wave_masked_supported(B->cols))
                 launch_wave_masked(b, ctx->ab, B->d_col_idx, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
                                    row_begin, ctx->tmp, ctx->cnt, sx);
-            else if (Fm)
-                HIPCHK_C(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
-                                                  ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
-            else if (b <= kWaveBins)
-                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
-                                 ctx->tmp, ctx->cnt, sx);
             else
-                HIPCHK_C(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
-                                           ctx->tmp, ctx->cnt, sx));
-            HIPCHK_C(hipEventRecord(ctx->ev_cls[k][b][1], sx));
+                HIPCHK_B(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
+                                                  ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
+            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
         }
-        HIPCHK_C(hipGetLastError());
-        HIPCHK_C(hipEventRecord(ctx->ev_tile[k][0], sB));
-        HIPCHK_C(hipStreamWaitEvent(s, ctx->ev_tile[k][0], 0));
-        if (nlanes > 2) {
-            HIPCHK_C(hipEventRecord(ctx->ev_tile[k][2], sC));
-            HIPCHK_C(hipStreamWaitEvent(s, ctx->ev_tile[k][2], 0));
+        HIPCHK_B(hipGetLastError());
+        for (int l = 1; l < nlanes; l++) {
+            HIPCHK_B(hipEventRecord(ctx->ev_tile[0][l], lanes[l]));
+            HIPCHK_B(hipStreamWaitEvent(s, ctx->ev_tile[0][l], 0));
         }
-        // counts -> row_ptr of this tile, continuing from the previous tile's last entry
-        launch_scan_counts(ctx->cnt + tb[k], tb[k + 1] - tb[k], C->d_row_ptr + tb[k], ctx->partials,
-                           k == 0 ? nullptr : C->d_row_ptr + tb[k], s);
-        HIPCHK_C(hipEventRecord(ctx->ev_tile[k][1], s));
-        HIPCHK_C(hipStreamWaitEvent(sC, ctx->ev_tile[k][1], 0));
-        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, tb[k], tb[k + 1], h->fb[k + 1] - h->fb[k],
-                       C->d_col_idx, sC);
-        HIPCHK_C(hipGetLastError());
+        HIPCHK_B(hipEventRecord(slot.ev[3], s));
+        launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, nullptr, s);
+        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, 0, R, total, C->d_col_idx, s);
+        HIPCHK_B(hipGetLastError());
+    } else {
+        HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
+        HIPCHK_B(hipEventRecord(slot.ev[3], s));
     }
-    if (R == 0) HIPCHK_C(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
-    HIPCHK_C(hipEventRecord(ctx->ev[2], s));
-    HIPCHK_C(hipEventRecord(ctx->ev_join, sC));
-    HIPCHK_C(hipStreamWaitEvent(s, ctx->ev_join, 0));
-    HIPCHK_C(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIPCHK_C(hipEventRecord(ctx->ev[3], s));
-    HIPCHK_C(hipStreamSynchronize(s));
+    HIPCHK_B(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[4], s));
+    HIPCHK_B(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
-#undef HIPCHK_C
-
-    bspgemm_stats &st = ctx->stats;
-    memset(&st, 0, sizeof st);
-    st.rows = R;
-    st.nnz_a = R > 0 ? (long long)h->a_hi - h->a_lo : 0;
-    st.products = (Fm && R > 0) ? h->products : totalF;
-    st.nnz_c = C->nnz;
-    st.bytes_alg = 4ll * (R + 1) + 12ll * st.nnz_a + 4ll * st.products + 4ll * C->nnz + 8ll * (R + 1);
-    static_assert(kMaxBins == BSPGEMM_MAX_BINS && kNumBins <= kMaxBins, "stats arrays hold every class");
-    st.bins = kNumBins;
-    for (int b = 0; b < kNumBins; b++) {
-        st.rows_per_bin[b] = h->bin_count[b];
-        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : 64 * kWaveChunks[b]);
-    }
-    hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[3]);
-    hipEventElapsedTime(&st.ms_symbolic, ctx->ev[0], ctx->ev[1]);
-    hipEventElapsedTime(&st.ms_numeric, ctx->ev[1], ctx->ev[2]);
-    hipEventElapsedTime(&st.ms_stitch, ctx->ev[2], ctx->ev[3]);
-    st.tiles = T;
-    for (int k = 0; k < T; k++)
-        for (int b = 1; b < kNumBins; b++)
-            if (cls_n[k][b] > 0) {
-                float ms = 0;
-                hipEventElapsedTime(&ms, ctx->ev_cls[k][b][0], ctx->ev_cls[k][b][1]);
-                st.ms_bin[b] += ms;
-            }
-    ctx->stats_valid = true;
+    close_slot(ctx, R, h, R > 0 ? h->products : 0, C->nnz, cls_n);
     *out = C;
     return BSPGEMM_OK;
 }
@@ -558,12 +739,9 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
                                            const bspgemm_matrix *B, int row_begin, int row_end,
                                            bspgemm_result **out)
 {
-    return multiply_impl(ctx, A, B, nullptr, row_begin, row_end, out);
+    return multiply_plain(ctx, A, B, row_begin, row_end, out);
 }
 
-// First implementation of the masked product: every non-empty row goes through the dense-window
-// kernel with a second (kept-bits) bitmap.  Correct for any shape; a mask-first rank-bitmap path
-// for short rows is the planned fast path.
 extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx, const bspgemm_matrix *A,
                                                   const bspgemm_matrix *B, const bspgemm_matrix *F,
                                                   int row_begin, int row_end, bspgemm_result **out)
@@ -572,7 +750,7 @@ extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx, const bs
         if (out) *out = nullptr;
         return FAIL(BSPGEMM_ERR_INVALID, "mask is NULL");
     }
-    return multiply_impl(ctx, A, B, F, row_begin, row_end, out);
+    return multiply_masked_impl(ctx, A, B, F, row_begin, row_end, out);
 }
 
 extern "C" int bspgemm_result_rows(const bspgemm_result *C) { return C ? C->rows : 0; }
@@ -608,11 +786,18 @@ extern "C" void bspgemm_result_free(bspgemm_result *C)
     delete C;
 }
 
+extern "C" bspgemm_status bspgemm_stats_at(const bspgemm_context *ctx, int age, bspgemm_stats *out)
+{
+    if (!ctx || !out || age < 0 || age >= bspgemm_context::kStatSlots) return FAIL(BSPGEMM_ERR_INVALID, "stats_at");
+    const int k = (ctx->slot_head - age % bspgemm_context::kStatSlots + bspgemm_context::kStatSlots) % bspgemm_context::kStatSlots;
+    if (!ctx->slots[k].used) return FAIL(BSPGEMM_ERR_INVALID, "no multiply of that age has completed on this context");
+    fill_stats(ctx->slots[k], *out);
+    return BSPGEMM_OK;
+}
+
 extern "C" bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out)
 {
-    if (!ctx || !out || !ctx->stats_valid) return FAIL(BSPGEMM_ERR_INVALID, "no multiply has run on this context");
-    *out = ctx->stats;
-    return BSPGEMM_OK;
+    return bspgemm_stats_at(ctx, 0, out);
 }
 
 // --------------------------------------------------------------- gathered lengths -> row_ptr -
@@ -652,12 +837,13 @@ extern "C" bspgemm_status bspgemm_matrix_from_result(bspgemm_context *ctx, const
     if (bspgemm_status st = use_device(ctx)) return st;
     bspgemm_matrix *m = new (std::nothrow) bspgemm_matrix{ctx, C->rows, cols, C->nnz, nullptr, nullptr, true};
     if (!m) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)C->rows + 1) * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int)));
+    auto bail = [&](bspgemm_status st) { bspgemm_matrix_free(m); return st; };
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr), ((size_t)C->rows + 1) * sizeof(int)));
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&m->d_col_idx), ((size_t)C->nnz + 1) * sizeof(int)));
     launch_narrow_row_ptr(C->d_row_ptr, m->d_row_ptr, C->rows + 1, ctx->stream);
     if (C->nnz > 0)
-        HIPCHK(hipMemcpyAsync(m->d_col_idx, C->d_col_idx, (size_t)C->nnz * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK_B(hipMemcpyAsync(m->d_col_idx, C->d_col_idx, (size_t)C->nnz * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK_B(hipStreamSynchronize(ctx->stream));
     *out = m;
     return BSPGEMM_OK;
 }
@@ -674,10 +860,13 @@ extern "C" bspgemm_status bspgemm_closure(bspgemm_context *ctx, const bspgemm_ma
     const int n = A->rows;
     bspgemm_matrix *cur = new (std::nothrow) bspgemm_matrix{ctx, n, n, A->nnz + n, nullptr, nullptr, true};
     if (!cur) return FAIL(BSPGEMM_ERR_ALLOC, "matrix");
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&cur->d_row_ptr), ((size_t)n + 1) * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&cur->d_col_idx), ((size_t)cur->nnz + 1) * sizeof(int)));
-    launch_add_diagonal(A->d_row_ptr, A->d_col_idx, n, cur->d_row_ptr, cur->d_col_idx, ctx->stream);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    {
+        auto bail = [&](bspgemm_status st) { bspgemm_matrix_free(cur); return st; };
+        HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&cur->d_row_ptr), ((size_t)n + 1) * sizeof(int)));
+        HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&cur->d_col_idx), ((size_t)cur->nnz + 1) * sizeof(int)));
+        launch_add_diagonal(A->d_row_ptr, A->d_col_idx, n, cur->d_row_ptr, cur->d_col_idx, ctx->stream);
+        HIPCHK_B(hipStreamSynchronize(ctx->stream));
+    }
     long long prev_nnz = -1;      // nnz of the deduplicated T(k); unknown for T0 (may hold duplicates)
     bspgemm_result *C = nullptr;
     bspgemm_status st = BSPGEMM_OK;
@@ -715,7 +904,7 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, 0, R, ctx->F, ctx->ab, ctx->stream);
     launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
-                        ctx->rec, ctx->recpre, ctx->cnt, ctx->stream);
+                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BSPGEMM_OK;
@@ -838,7 +1027,10 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
                 dst = *Ccol;
                 if (!dst || !Csize || *Csize < nnz) {
                     dst = static_cast<int *>(realloc(*Ccol, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int)));
-                    if (dst && Csize) *Csize = (int)(nnz > 0 ? nnz : 1);
+                    if (dst) {                          // published at once: realloc has freed or moved the old block
+                        *Ccol = dst;
+                        if (Csize) *Csize = (int)(nnz > 0 ? nnz : 1);
+                    }
                     advise_huge(dst, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int));
                 }
             } else {
@@ -905,14 +1097,23 @@ extern "C" int SpGEMM_hip_masked(int *Acol, int *Arow, int An, int *Bcol, int *B
 }
 
 // ------------------------------------------------------------------ multi-GPU stitch -----
+// One protocol, two transports.  Every rank contributes the int32 LENGTHS of its shard's rows,
+// padded to the longest shard; one all-gather; every rank scans the gathered lengths into the
+// global int64 C.row_ptr on its device (bspgemm_lengths_to_row_ptr).  The all-gather is RCCL over
+// xGMI (bspgemm_comm_create) or a host callback (bspgemm_comm_create_host: MPI_Allgather in the C
+// drivers when ranks share a GPU, a fake in the tests) -- everything around it is the same code.
 struct bspgemm_comm {
     bspgemm_context *ctx;
-    ncclComm_t comm;
+    ncclComm_t comm;                    // RCCL transport (NULL with the host transport)
+    bspgemm_host_transport host;        // host transport callbacks (allgather NULL with RCCL)
     int rank, nranks;
-    long long *d_nnz;      // nranks
-    int *d_bounds;         // nranks+1
-    long long *d_global;   // stitched row_ptr, grown on demand
-    size_t global_cap;
+    int *d_send = nullptr;              // width ints
+    int *d_recv = nullptr;              // nranks * width ints
+    size_t width_cap = 0;
+    long long *d_global = nullptr;      // stitched row_ptr, grown on demand
+    size_t global_cap = 0;
+    long long *d_edges = nullptr;       // global row_ptr at the shard bounds (nranks + 1)
+    int *d_bounds = nullptr;            // nranks + 1
 };
 
 extern "C" bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES])
@@ -925,19 +1126,68 @@ extern "C" bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE
     return BSPGEMM_OK;
 }
 
+static bspgemm_status comm_new(bspgemm_context *ctx, int rank, int nranks, bspgemm_comm **out)
+{
+    bspgemm_comm *c = new (std::nothrow) bspgemm_comm();
+    if (!c) return FAIL(BSPGEMM_ERR_ALLOC, "comm");
+    c->ctx = ctx;
+    c->comm = nullptr;
+    c->host = bspgemm_host_transport{nullptr, nullptr, nullptr};
+    c->rank = rank;
+    c->nranks = nranks;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_edges), ((size_t)nranks + 1) * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_bounds), ((size_t)nranks + 1) * sizeof(int));
+    if (e != hipSuccess) {
+        bspgemm_comm_destroy(c);
+        snprintf(g_err, sizeof g_err, "comm buffers: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? BSPGEMM_ERR_ALLOC : BSPGEMM_ERR_HIP;
+    }
+    *out = c;
+    return BSPGEMM_OK;
+}
+
 extern "C" bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[BSPGEMM_UNIQUE_ID_BYTES],
                                               int rank, int nranks, bspgemm_comm **out)
 {
     if (!ctx || !id || !out || nranks <= 0 || rank < 0 || rank >= nranks) return FAIL(BSPGEMM_ERR_INVALID, "comm_create");
     *out = nullptr;
     if (bspgemm_status st = use_device(ctx)) return st;
-    bspgemm_comm *c = new (std::nothrow) bspgemm_comm{ctx, nullptr, rank, nranks, nullptr, nullptr, nullptr, 0};
-    if (!c) return FAIL(BSPGEMM_ERR_ALLOC, "comm");
+    bspgemm_comm *c = nullptr;
+    if (bspgemm_status st = comm_new(ctx, rank, nranks, &c)) return st;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    NCCLCHK(ncclCommInitRank(&c->comm, nranks, u, rank));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_nnz), (size_t)nranks * sizeof(long long)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_bounds), ((size_t)nranks + 1) * sizeof(int)));
+    // RCCL prints a version banner on STDOUT when the first communicator is created; the drop-in
+    // binaries' stdout is the reference's CSV line / parity message and nothing else, so the
+    // banner is sent to stderr
+    fflush(stdout);
+    const int saved_out = dup(1);
+    if (saved_out >= 0) dup2(2, 1);
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+    if (saved_out >= 0) {
+        fflush(stdout);
+        dup2(saved_out, 1);
+        close(saved_out);
+    }
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        bspgemm_comm_destroy(c);
+        snprintf(g_err, sizeof g_err, "ncclCommInitRank: %s", ncclGetErrorString(r));
+        return BSPGEMM_ERR_COMM;
+    }
+    *out = c;
+    return BSPGEMM_OK;
+}
+
+extern "C" bspgemm_status bspgemm_comm_create_host(bspgemm_context *ctx, const bspgemm_host_transport *t,
+                                                   int rank, int nranks, bspgemm_comm **out)
+{
+    if (!ctx || !t || !t->allgather || !out || nranks <= 0 || rank < 0 || rank >= nranks)
+        return FAIL(BSPGEMM_ERR_INVALID, "comm_create_host");
+    *out = nullptr;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    bspgemm_comm *c = nullptr;
+    if (bspgemm_status st = comm_new(ctx, rank, nranks, &c)) return st;
+    c->host = *t;
     *out = c;
     return BSPGEMM_OK;
 }
@@ -947,23 +1197,37 @@ extern "C" void bspgemm_comm_destroy(bspgemm_comm *c)
     if (!c) return;
     hipSetDevice(c->ctx->device);
     if (c->comm) ncclCommDestroy(c->comm);
-    hipFree(c->d_nnz);
-    hipFree(c->d_bounds);
+    hipFree(c->d_send);
+    hipFree(c->d_recv);
     hipFree(c->d_global);
+    hipFree(c->d_edges);
+    hipFree(c->d_bounds);
     delete c;
 }
 
-// global[i] += sum of shard nnz before the shard that owns row i; global[total_rows] = grand total
-__global__ void k_stitch_rebase(long long *global, const int *bounds, const long long *shard_nnz, int nranks)
+extern "C" int bspgemm_comm_rank(const bspgemm_comm *c) { return c ? c->rank : -1; }
+extern "C" int bspgemm_comm_size(const bspgemm_comm *c) { return c ? c->nranks : 0; }
+
+// lengths[i] = row_ptr[i+1] - row_ptr[i]  (|C_i| < 2^31 always; the slice-local offsets are not)
+__global__ void k_row_lengths(const long long *__restrict__ row_ptr, int n, int *__restrict__ len)
 {
-    const int total_rows = bounds[nranks];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > total_rows) return;
-    long long base = 0;
-    int r = 0;
-    while (r < nranks && i >= bounds[r + 1]) { base += shard_nnz[r]; r++; }
-    if (i == total_rows) global[i] = base;
-    else global[i] += base;
+    if (i < n) len[i] = (int)(row_ptr[i + 1] - row_ptr[i]);
+}
+// edges[r] = global[bounds[r]]
+__global__ void k_pick_edges(const long long *__restrict__ global, const int *__restrict__ bounds, int n,
+                             long long *__restrict__ edges)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) edges[r] = global[bounds[r]];
+}
+
+static bspgemm_status comm_bounds_ok(const bspgemm_comm *c, const int *bounds)
+{
+    if (bounds[0] != 0) return FAIL(BSPGEMM_ERR_INVALID, "bounds[0] != 0");
+    for (int r = 0; r < c->nranks; r++)
+        if (bounds[r + 1] < bounds[r]) return FAIL(BSPGEMM_ERR_INVALID, "bounds not ascending");
+    return BSPGEMM_OK;
 }
 
 extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bspgemm_result *local,
@@ -971,40 +1235,188 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
                                                       int64_t *shard_nnz)
 {
     if (!c || !local || !bounds || !d_row_ptr_global) return FAIL(BSPGEMM_ERR_INVALID, "stitch_row_ptr");
-    bspgemm_context *ctx = c->ctx;
-    if (bspgemm_status st = use_device(ctx)) return st;
-    const size_t need = (size_t)bounds[c->nranks] + 1;
-    if (need > c->global_cap) {
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        hipFree(c->d_global);
-        c->d_global = nullptr;
-        c->global_cap = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_global), need * sizeof(long long)));
-        c->global_cap = need;
-    }
-    long long *global = c->d_global;
-    *d_row_ptr_global = reinterpret_cast<const int64_t *>(global);
+    if (bspgemm_status st = comm_bounds_ok(c, bounds)) return st;
     const int my_rows = bounds[c->rank + 1] - bounds[c->rank];
     if (my_rows != local->rows) return FAIL(BSPGEMM_ERR_INVALID, "local result does not match bounds[rank]");
+    bspgemm_context *ctx = c->ctx;
+    if (bspgemm_status st = use_device(ctx)) return st;
     hipStream_t s = ctx->stream;
-    HIPCHK(hipMemcpyAsync(c->d_bounds, bounds, ((size_t)c->nranks + 1) * sizeof(int), hipMemcpyHostToDevice, s));
-    // shard sizes: every rank contributes row_ptr[rows] (its nnz), 8 bytes
-    NCCLCHK(ncclAllGather(local->d_row_ptr + local->rows, c->d_nnz, 1, ncclInt64, c->comm, s));
-    // row_ptr shards have different lengths (equal-work cuts), so one broadcast per shard, grouped
-    NCCLCHK(ncclGroupStart());
-    for (int r = 0; r < c->nranks; r++) {
-        const int n = bounds[r + 1] - bounds[r];
-        if (n <= 0) continue;
-        long long *dst = global + bounds[r];
-        const void *src = (r == c->rank) ? static_cast<const void *>(local->d_row_ptr) : static_cast<const void *>(dst);
-        NCCLCHK(ncclBroadcast(src, dst, (size_t)n, ncclInt64, r, c->comm, s));
+    int width = 1;
+    for (int r = 0; r < c->nranks; r++)
+        if (bounds[r + 1] - bounds[r] > width) width = bounds[r + 1] - bounds[r];
+    const size_t need = (size_t)bounds[c->nranks] + 1;
+    if ((size_t)width > c->width_cap || need > c->global_cap) {
+        HIPCHK(hipStreamSynchronize(s));
+        if ((size_t)width > c->width_cap) {
+            hipFree(c->d_send); hipFree(c->d_recv);
+            c->d_send = c->d_recv = nullptr;
+            c->width_cap = 0;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_send), (size_t)width * sizeof(int)));
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_recv), (size_t)width * c->nranks * sizeof(int)));
+            c->width_cap = (size_t)width;
+        }
+        if (need > c->global_cap) {
+            hipFree(c->d_global);
+            c->d_global = nullptr;
+            c->global_cap = 0;
+            HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_global), need * sizeof(long long)));
+            c->global_cap = need;
+        }
     }
-    NCCLCHK(ncclGroupEnd());
-    const int total_rows = bounds[c->nranks];
-    hipLaunchKernelGGL(k_stitch_rebase, dim3((total_rows + 1 + 255) / 256), dim3(256), 0, s,
-                       global, c->d_bounds, c->d_nnz, c->nranks);
-    if (shard_nnz)
-        HIPCHK(hipMemcpyAsync(shard_nnz, c->d_nnz, (size_t)c->nranks * sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // 1. this shard's row lengths (pad slots are never read by the scan)
+    if (my_rows > 0)
+        hipLaunchKernelGGL(k_row_lengths, dim3((my_rows + 255) / 256), dim3(256), 0, s, local->d_row_ptr, my_rows, c->d_send);
+    // 2. the one collective
+    if (c->comm) {
+        NCCLCHK(ncclAllGather(c->d_send, c->d_recv, (size_t)width, ncclInt32, c->comm, s));
+    } else {
+        const size_t bytes = (size_t)width * sizeof(int);
+        int *hs = static_cast<int *>(malloc(bytes)), *hr = static_cast<int *>(malloc(bytes * c->nranks));
+        bspgemm_status st = (hs && hr) ? BSPGEMM_OK : FAIL(BSPGEMM_ERR_ALLOC, "host staging");
+        if (!st && hipMemcpyAsync(hs, c->d_send, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) st = FAIL(BSPGEMM_ERR_HIP, "lengths to host");
+        if (!st && hipStreamSynchronize(s) != hipSuccess) st = FAIL(BSPGEMM_ERR_HIP, "sync");
+        if (!st && c->host.allgather(c->host.user, hs, hr, bytes) != 0) st = FAIL(BSPGEMM_ERR_COMM, "host all-gather failed");
+        if (!st && hipMemcpyAsync(c->d_recv, hr, bytes * c->nranks, hipMemcpyHostToDevice, s) != hipSuccess) st = FAIL(BSPGEMM_ERR_HIP, "lengths to device");
+        if (!st && hipStreamSynchronize(s) != hipSuccess) st = FAIL(BSPGEMM_ERR_HIP, "sync");
+        free(hs); free(hr);
+        if (st) return st;
+    }
+    // 3. every rank scans the gathered lengths: shard r continues where shard r-1 ended
+    if (bspgemm_status st = bspgemm_lengths_to_row_ptr(ctx, c->d_recv, c->nranks, width, bounds,
+                                                       reinterpret_cast<int64_t *>(c->d_global), s))
+        return st;
+    *d_row_ptr_global = reinterpret_cast<const int64_t *>(c->d_global);
+    if (shard_nnz) {
+        HIPCHK(hipMemcpyAsync(c->d_bounds, bounds, ((size_t)c->nranks + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pick_edges, dim3(1), dim3(c->nranks + 1 <= 1024 ? c->nranks + 1 : 1024), 0, s,
+                           c->d_global, c->d_bounds, c->nranks + 1, c->d_edges);
+        long long edges[1025];
+        if (c->nranks > 1024) return FAIL(BSPGEMM_ERR_INVALID, "more than 1024 ranks");
+        HIPCHK(hipMemcpyAsync(edges, c->d_edges, ((size_t)c->nranks + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int r = 0; r < c->nranks; r++) shard_nnz[r] = edges[r + 1] - edges[r];
+    } else {
+        HIPCHK(hipStreamSynchronize(s));
+    }
     return BSPGEMM_OK;
+}
+
+// Root gather of the sharded col_idx (what MPI_Gatherv does at final/SpGEMM_mpi_omp.c:203): with
+// RCCL every rank sends its shard and the root receives them at their global offsets -- one
+// grouped send/recv, the root's own shard included, so that one rank runs the same calls as N.
+extern "C" bspgemm_status bspgemm_comm_gather_col_idx(bspgemm_comm *c, const bspgemm_result *local,
+                                                      const int64_t *shard_nnz, int root, int *col_idx_host)
+{
+    if (!c || !local || !shard_nnz || root < 0 || root >= c->nranks) return FAIL(BSPGEMM_ERR_INVALID, "gather_col_idx");
+    if (shard_nnz[c->rank] != local->nnz) return FAIL(BSPGEMM_ERR_INVALID, "shard_nnz[rank] != nnz of the local result");
+    bspgemm_context *ctx = c->ctx;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    hipStream_t s = ctx->stream;
+    long long total = 0;
+    for (int r = 0; r < c->nranks; r++) total += shard_nnz[r];
+    if (c->rank == root && total > 0 && !col_idx_host) return FAIL(BSPGEMM_ERR_INVALID, "root needs a destination");
+    if (c->comm) {
+        int *d_all = nullptr;
+        if (c->rank == root)
+            HIPCHK(result_alloc(ctx, reinterpret_cast<void **>(&d_all), result_bytes_colidx(total)));
+        ncclResult_t nr = ncclGroupStart();
+        if (nr == ncclSuccess && local->nnz > 0)
+            nr = ncclSend(local->d_col_idx, (size_t)local->nnz, ncclInt32, root, c->comm, s);
+        if (c->rank == root) {
+            long long off = 0;
+            for (int r = 0; r < c->nranks && nr == ncclSuccess; r++) {
+                if (shard_nnz[r] > 0) nr = ncclRecv(d_all + off, (size_t)shard_nnz[r], ncclInt32, r, c->comm, s);
+                off += shard_nnz[r];
+            }
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        bspgemm_status st = BSPGEMM_OK;
+        if (nr != ncclSuccess) {
+            snprintf(g_err, sizeof g_err, "col_idx gather: %s", ncclGetErrorString(nr));
+            st = BSPGEMM_ERR_COMM;
+        }
+        if (!st && c->rank == root && total > 0 &&
+            hipMemcpyAsync(col_idx_host, d_all, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)
+            st = FAIL(BSPGEMM_ERR_HIP, "gathered col_idx to host");
+        if (hipStreamSynchronize(s) != hipSuccess && !st) st = FAIL(BSPGEMM_ERR_HIP, "sync");
+        if (d_all) result_release(ctx, d_all, result_bytes_colidx(total));
+        return st;
+    }
+    if (!c->host.gatherv) return FAIL(BSPGEMM_ERR_INVALID, "host transport has no gatherv");
+    int *mine = static_cast<int *>(malloc((size_t)(local->nnz > 0 ? local->nnz : 1) * sizeof(int)));
+    if (!mine) return FAIL(BSPGEMM_ERR_ALLOC, "host shard");
+    bspgemm_status st = bspgemm_result_download(ctx, local, nullptr, mine);
+    if (!st) {
+        size_t *bytes = static_cast<size_t *>(malloc((size_t)c->nranks * sizeof(size_t)));
+        if (!bytes) st = FAIL(BSPGEMM_ERR_ALLOC, "counts");
+        else {
+            for (int r = 0; r < c->nranks; r++) bytes[r] = (size_t)shard_nnz[r] * sizeof(int);
+            if (c->host.gatherv(c->host.user, mine, (size_t)local->nnz * sizeof(int), col_idx_host, bytes, root) != 0)
+                st = FAIL(BSPGEMM_ERR_COMM, "host gatherv failed");
+            free(bytes);
+        }
+    }
+    free(mine);
+    return st;
+}
+
+// replaces SpGEMM_mpi (final/SpGEMM_mpi_omp.c:155-225): same arguments plus the communicator the
+// reference takes implicitly (MPI_COMM_WORLD).  Every rank passes the whole A and B (every rank of
+// the reference reads the whole file, :309); rows are cut at equal work instead of An/numtasks
+// (:165); the result -- malloc'ed *Ccol, caller's Crow[An+1] -- is valid on rank 0 only, like :200-223.
+extern "C" int SpGEMM_hip_multi(bspgemm_comm *c, int *Acol, int *Arow, int An, int *Bcol, int *Brow, int Bm,
+                                int **Ccol, int *Crow, int tBlock)
+{
+    (void)tBlock;
+    if (Ccol) *Ccol = nullptr;
+    auto run = [&]() -> bspgemm_status {
+        if (!c || !Acol || !Arow || !Bcol || !Brow || !Ccol || !Crow || An < 0 || Bm < 0)
+            return FAIL(BSPGEMM_ERR_INVALID, "SpGEMM_hip_multi arguments");
+        bspgemm_context *ctx = c->ctx;
+        const int brows = bspgemm_par_max_plus_one(Acol + Arow[0], (long long)Arow[An] - Arow[0]);
+        bspgemm_matrix *A = nullptr, *B = nullptr;
+        bspgemm_result *C = nullptr;
+        int *bounds = static_cast<int *>(malloc(((size_t)c->nranks + 1) * sizeof(int)));
+        int64_t *shard = static_cast<int64_t *>(malloc((size_t)c->nranks * sizeof(int64_t)));
+        int64_t *rp64 = nullptr;
+        int *dst = nullptr;
+        bspgemm_status st = (bounds && shard) ? BSPGEMM_OK : FAIL(BSPGEMM_ERR_ALLOC, "bounds");
+        if (!st) st = bspgemm_matrix_upload(ctx, An, brows, Arow, Acol, &A);
+        if (!st) st = bspgemm_matrix_upload(ctx, brows, Bm, Brow, Bcol, &B);
+        if (!st) st = bspgemm_partition_rows(ctx, A, B, c->nranks, bounds);
+        if (!st) st = bspgemm_multiply(ctx, A, B, bounds[c->rank], bounds[c->rank + 1], &C);
+        const int64_t *d_global = nullptr;
+        if (!st) st = bspgemm_comm_stitch_row_ptr(c, C, bounds, &d_global, shard);
+        long long total = 0;
+        if (!st) {
+            for (int r = 0; r < c->nranks; r++) total += shard[r];
+            if (total > INT_MAX) st = FAIL(BSPGEMM_ERR_OVERFLOW, "nnz(C) > INT_MAX: use the int64 handle API");
+        }
+        if (!st && c->rank == 0) {
+            dst = static_cast<int *>(malloc((size_t)(total > 0 ? total : 1) * sizeof(int)));
+            rp64 = static_cast<int64_t *>(malloc(((size_t)An + 1) * sizeof(int64_t)));
+            if (!dst || !rp64) st = FAIL(BSPGEMM_ERR_ALLOC, "host result");
+        }
+        // (a root that failed to allocate still takes part in the gather so that no rank hangs)
+        bspgemm_status gst = BSPGEMM_OK;
+        if (C && d_global && total <= INT_MAX) gst = bspgemm_comm_gather_col_idx(c, C, shard, 0, dst);
+        if (!st) st = gst;
+        if (!st && c->rank == 0) {
+            if (hipMemcpy(rp64, d_global, ((size_t)An + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+                st = FAIL(BSPGEMM_ERR_HIP, "row_ptr to host");
+            else {
+                for (int i = 0; i <= An; i++) Crow[i] = (int)rp64[i];
+                *Ccol = dst;
+                dst = nullptr;
+            }
+        }
+        free(dst); free(rp64); free(bounds); free(shard);
+        bspgemm_result_free(C);
+        bspgemm_matrix_free(A);
+        bspgemm_matrix_free(B);
+        return st;
+    };
+    const bspgemm_status st = run();
+    return st ? dropin_fail("SpGEMM_hip_multi", st) : 0;
 }

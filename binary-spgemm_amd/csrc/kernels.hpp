@@ -70,18 +70,31 @@ void launch_row_work(const int *Arow, const int *Acol, const int *Brow,
 // exclusive scan of F (int64) into prefix[0..n] and, fused, classification of every row into
 // the capacity classes: rec[] holds the non-empty rows grouped by class (class b starts at
 // sum(bin_count[1..b-1])), recpre[] their output offsets; bin_count[8] on the device.
+// heavy_cols > 0: the heavy rows (class kDenseBin) get their own workspace offsets in recpre --
+// exclusive prefix of min(F_i, heavy_cols) over the heavy rows -- and hpartials[ceil(n/2048)]
+// holds that workspace's total size; one-wave rows are then placed by the symbolic counts.
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, hipStream_t s);
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, hipStream_t s);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
                         const long long *base, hipStream_t s);
 
-// numeric phase, one wave per row (rank-bitmap accumulator)
+// symbolic phase, one wave per row: cnt[row] = |C_row| exactly (hash set in LDS, nothing emitted)
+void launch_wave_count(int bin, const int2 *ab, const int *Bcol, int cols, const RowRec *rec, int nrows,
+                       int row_begin, int *cnt, hipStream_t s);
+
+// numeric phase, one wave per row (rank-bitmap accumulator).  row_ptr != NULL: row i is written at
+// tmp + row_ptr[i - row_begin] (tmp = C.col_idx, sizes known from the symbolic phase, cnt may be
+// NULL); row_ptr == NULL: at its upper-bound offset tmp + recpre[k], |C_i| to cnt (masked product)
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
-                      const RowRec *rec, const long long *recpre, int nrows, int row_begin,
-                      int *tmp, int *cnt, hipStream_t s);
+                      const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
+                      int row_begin, int *tmp, int *cnt, hipStream_t s);
+
+// heavy rows: workspace -> final place (one workgroup per heavy row)
+void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,
+                        const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s);
 
 // numeric phase, one workgroup per heavy row (windowed dense LDS bitmap)
 hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,

@@ -97,29 +97,43 @@ __device__ __forceinline__ int bin_of(long long F)
     return b;
 }
 
+// `heavy_cols` > 0 (BIN only): hpartials[tile] = sum over the tile's heavy rows of min(F_i, heavy_cols),
+// the room a heavy row can need in the heavy-row workspace (|C_i| <= min(F_i, cols))
 template <typename T, bool BIN>
 __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict__ in, int n,
                                                             long long *__restrict__ partials,
-                                                            int *__restrict__ bin_tiles)
+                                                            int *__restrict__ bin_tiles,
+                                                            int heavy_cols, long long *__restrict__ hpartials)
 {
-    __shared__ long long lds[4];
+    __shared__ long long lds[4], ldh[4];
     __shared__ int lcount[kNumBins];
     if (BIN && threadIdx.x < kNumBins) lcount[threadIdx.x] = 0;
     if (BIN) __syncthreads();
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    long long v = 0;
+    long long v = 0, hv = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++)
         if (base + k < n) {
             const long long x = (long long)in[base + k];
             v += x;
-            if (BIN) atomicAdd(&lcount[bin_of(x)], 1);
+            if (BIN) {
+                const int b = bin_of(x);
+                atomicAdd(&lcount[b], 1);
+                if (b == kDenseBin) hv += x < heavy_cols ? x : heavy_cols;
+            }
         }
     v = wave_incl_scan64(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) lds[w] = v;
+    if (BIN && heavy_cols > 0) {
+        hv = wave_incl_scan64(hv);
+        if (lane == 63) ldh[w] = hv;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+        if (BIN && heavy_cols > 0) hpartials[blockIdx.x] = ldh[0] + ldh[1] + ldh[2] + ldh[3];
+    }
     if (BIN && threadIdx.x < kNumBins) bin_tiles[blockIdx.x * kNumBins + threadIdx.x] = lcount[threadIdx.x];
 }
 
@@ -151,15 +165,19 @@ __device__ __forceinline__ void scan_column(V *vals, int m, int stride, long lon
     if (threadIdx.x == 0) vals[(size_t)m * stride] = (V)*carry_s;
 }
 
-// block 0 scans the tile sums; blocks 1..8 (BIN only) scan one capacity class's per-tile counts
+// block 0 scans the tile sums; blocks 1..kNumBins (BIN only) scan one capacity class's per-tile
+// counts; block kNumBins+1 (heavy-row workspace in use) scans the heavy-row bounds
 __global__ __launch_bounds__(1024) void k_scan_partials(long long *__restrict__ partials, int m,
                                                         int *__restrict__ bin_tiles,
-                                                        int *__restrict__ bin_count)
+                                                        int *__restrict__ bin_count,
+                                                        long long *__restrict__ hpartials)
 {
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     if (blockIdx.x == 0) {
         scan_column<long long>(partials, m, 1, wsum, &carry_s);
+    } else if (blockIdx.x == kNumBins + 1) {
+        scan_column<long long>(hpartials, m, 1, wsum, &carry_s);
     } else {
         const int b = blockIdx.x - 1;
         scan_column<int>(bin_tiles + b, m, kNumBins, wsum, &carry_s);
@@ -168,10 +186,12 @@ __global__ __launch_bounds__(1024) void k_scan_partials(long long *__restrict__ 
     }
 }
 
+// `out` and `carry_in` may alias (a row range continuing the row_ptr of the rows before it hands
+// out[0] in as the carry): neither is __restrict__.
 template <typename T, bool BIN>
 __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict__ in, int n,
                                                              const long long *__restrict__ partials,
-                                                             long long *__restrict__ out,
+                                                             long long *out,
                                                              int row_begin,
                                                              const int *__restrict__ Arow,
                                                              const int *__restrict__ bin_tiles,
@@ -179,18 +199,21 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              RowRec *__restrict__ rec,
                                                              long long *__restrict__ recpre,
                                                              int *__restrict__ cnt,
-                                                             const long long *__restrict__ carry_in)
+                                                             const long long *carry_in,
+                                                             int heavy_cols,
+                                                             const long long *__restrict__ hpartials)
 {
-    __shared__ long long wsum[4];
+    __shared__ long long wsum[4], hsum[4];
     __shared__ int lcount[kNumBins];
     __shared__ int lbase[kNumBins];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     long long v[kScanItems];
-    long long tsum = 0;
+    long long tsum = 0, hmine = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         v[k] = (base + k < n) ? (long long)in[base + k] : 0;
         tsum += v[k];
+        if (BIN && v[k] > kMaxWaveCap) hmine += v[k] < heavy_cols ? v[k] : heavy_cols;
     }
     if (BIN && threadIdx.x < kNumBins) {
         // segment start of class b in the record array (class 0 = empty rows has no records)
@@ -202,10 +225,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
     const long long inc = wave_incl_scan64(tsum);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) wsum[w] = inc;
+    long long hoff = 0;
+    if (BIN && heavy_cols > 0) {                               // uniform
+        const long long hinc = wave_incl_scan64(hmine);
+        if (lane == 63) hsum[w] = hinc;
+        hoff = hinc - hmine;
+    }
     __syncthreads();
     const long long base0 = carry_in ? *carry_in : 0;     // carry of the rows before this range
     long long off = base0 + partials[blockIdx.x] + inc - tsum;
     for (int k = 0; k < w; k++) off += wsum[k];
+    if (BIN && heavy_cols > 0) {
+        hoff += hpartials[blockIdx.x];
+        for (int k = 0; k < w; k++) hoff += hsum[k];
+    }
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         if (base + k < n) {
@@ -224,7 +257,10 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                     q.alen = Arow[row + 1] - a0;
                     q.f = v[k] > 0x7fffffffll ? 0x7fffffff : (int)v[k];
                     rec[pos] = q;
-                    recpre[pos] = off;
+                    // where the row is first written: its upper-bound offset, or (heavy-row workspace
+                    // in use) the heavy rows' own offsets; one-wave rows then never use recpre
+                    recpre[pos] = (heavy_cols > 0 && b == kDenseBin) ? hoff : off;
+                    if (heavy_cols > 0 && b == kDenseBin) hoff += v[k] < heavy_cols ? v[k] : heavy_cols;
                 }
             }
         }
@@ -235,26 +271,29 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, hipStream_t s)
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, hipStream_t s)
 {
     if (n <= 0) {
         hipMemsetAsync(prefix, 0, sizeof(long long), s);
         hipMemsetAsync(bin_count, 0, kNumBins * sizeof(int), s);
+        if (heavy_cols > 0) hipMemsetAsync(hpartials, 0, sizeof(long long), s);
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1 + kNumBins), dim3(1024), 0, s, partials, tiles, bin_tiles, bin_count);
+    hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles,
+                       heavy_cols, hpartials);
+    hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0, s, partials,
+                       tiles, bin_tiles, bin_count, hpartials);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
-                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr);
+                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials);
 }
 
 void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s)
 {
     if (n <= 0) { hipMemsetAsync(partials, 0, sizeof(long long), s); return; }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
 }
 
 // prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
@@ -267,10 +306,10 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -10,9 +10,15 @@
  * object "matrix", format coordinate|array, field real|complex|pattern|integer, symmetry
  * general|symmetric|hermitian|skew-symmetric; field and symmetry are then ignored for the
  * structure (symmetric files are NOT expanded), n = M.
- * Differences: failures are returned, not exit(1)'d (the CLI re-creates the exits); the file is
- * parsed from one buffer instead of nnz fscanf calls; for real/integer/complex files the value
- * tokens are skipped instead of being mis-read as coordinates (:68 reads exactly two %u).
+ * Differences: failures are returned, not exit(1)'d (the CLI re-creates the exits, including which
+ * of them print: a rejected banner is BSPGEMM_ERR_FORMAT, a rejected size line or entry
+ * BSPGEMM_ERR_SIZE); the file is parsed from one buffer instead of nnz fscanf calls; for
+ * real/integer/complex files the value tokens are skipped instead of being mis-read as
+ * coordinates (:68 reads exactly two %u).
+ * bspgemm_readCOO_ex adds, opt-in, what the reference leaves out: with
+ * BSPGEMM_READ_EXPAND_SYMMETRIC the stored triangle of a symmetric / hermitian / skew-symmetric
+ * file is mirrored (every off-diagonal entry (i,j) also gives (j,i), right behind it in file
+ * order), so the CSR is the full pattern.  Without the flag the result is the reference's.
  */
 #include "../../include/bspgemm.h"
 
@@ -59,8 +65,8 @@ static const char *next_line(const char *p, const char *end)
     return p < end ? p + 1 : end;
 }
 
-bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
-                               uint32_t *M, uint32_t *N, uint32_t *nnz)
+bspgemm_status bspgemm_readCOO_ex(const char *path, unsigned flags, uint32_t **row, uint32_t **col,
+                                  uint32_t *M, uint32_t *N, uint32_t *nnz)
 {
     if (!path || !row || !col || !M || !N || !nnz) return BSPGEMM_ERR_INVALID;
     *row = *col = NULL;
@@ -100,6 +106,7 @@ bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
         free(buf);
         return BSPGEMM_ERR_FORMAT;
     }
+    const int mirror = (flags & BSPGEMM_READ_EXPAND_SYMMETRIC) && !ieq(ss, "general");
 
     /* ---- size line (mmio.c:189-217): skip '%' lines, then three integers ---- */
     while (p < end && *p == '%') p = next_line(p, end);
@@ -108,32 +115,42 @@ bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
         const char *q = parse_u(p, end, &m);
         if (q) q = parse_u(q, end, &n);
         if (q) q = parse_u(q, end, &nz);
-        if (!q) { free(buf); return BSPGEMM_ERR_FORMAT; }
+        if (!q) { free(buf); return BSPGEMM_ERR_SIZE; }                /* utils.c:60-61: exit(1), nothing printed */
         p = q;
     }
-    if (m > 0x7fffffffull || n > 0x7fffffffull || nz > 0x7fffffffull) { free(buf); return BSPGEMM_ERR_FORMAT; }
+    if (m > 0x7fffffffull || n > 0x7fffffffull || nz > 0x7fffffffull) { free(buf); return BSPGEMM_ERR_SIZE; }
+    if (mirror && 2 * nz > 0x7fffffffull) { free(buf); return BSPGEMM_ERR_SIZE; }
 
     /* ---- entries (utils.c:66-71) + coo2csc with swapped roles (utils.c:77) ---- */
     const size_t dim = (size_t)(m > n ? m : n);          /* the reference assumes square (coo2csc.c:18) */
-    uint32_t *I = malloc((size_t)(nz ? nz : 1) * sizeof(uint32_t));
-    uint32_t *J = malloc((size_t)(nz ? nz : 1) * sizeof(uint32_t));
+    const size_t cap = (size_t)(nz ? nz : 1) * (mirror ? 2 : 1);
+    uint32_t *I = malloc(cap * sizeof(uint32_t));
+    uint32_t *J = malloc(cap * sizeof(uint32_t));
     uint32_t *rp = calloc(dim + 2, sizeof(uint32_t));
-    uint32_t *ci = malloc((size_t)(nz ? nz : 1) * sizeof(uint32_t));
-    if (!I || !J || !rp || !ci) { free(I); free(J); free(rp); free(ci); free(buf); return BSPGEMM_ERR_ALLOC; }
-    for (unsigned long long e = 0; e < nz; e++) {
+    uint32_t *ci = NULL;
+    if (!I || !J || !rp) { free(I); free(J); free(rp); free(buf); return BSPGEMM_ERR_ALLOC; }
+    const unsigned long long file_nz = nz;
+    nz = 0;
+    for (unsigned long long e = 0; e < file_nz; e++) {
         unsigned long long a = 1, b = 1;
         const char *q = parse_u(p, end, &a);
         if (q) q = parse_u(q, end, &b);
         if (!q || a < 1 || b < 1 || a > dim || b > dim) {
-            free(I); free(J); free(rp); free(ci); free(buf);
-            return BSPGEMM_ERR_FORMAT;
+            free(I); free(J); free(rp); free(buf);
+            return BSPGEMM_ERR_SIZE;
         }
         for (int x = 0; x < extra; x++) q = skip_token(q, end);
         p = q;
-        I[e] = (uint32_t)(a - 1);                                   /* 1-based -> 0-based */
-        J[e] = (uint32_t)(b - 1);
+        I[nz] = (uint32_t)(a - 1);                                  /* 1-based -> 0-based */
+        J[nz++] = (uint32_t)(b - 1);
+        if (mirror && a != b) {                                     /* the other triangle */
+            I[nz] = (uint32_t)(b - 1);
+            J[nz++] = (uint32_t)(a - 1);
+        }
     }
     free(buf);
+    ci = malloc((size_t)(nz ? nz : 1) * sizeof(uint32_t));
+    if (!ci) { free(I); free(J); free(rp); return BSPGEMM_ERR_ALLOC; }
     for (unsigned long long e = 0; e < nz; e++) rp[J[e] + 1]++;     /* coo2csc.c:37-39 */
     for (size_t i = 0; i < dim; i++) rp[i + 1] += rp[i];            /* :42-47 */
     uint32_t *cur = malloc((dim + 1) * sizeof(uint32_t));
@@ -146,6 +163,12 @@ bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
     return BSPGEMM_OK;
 }
 
+bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
+                               uint32_t *M, uint32_t *N, uint32_t *nnz)
+{
+    return bspgemm_readCOO_ex(path, 0u, row, col, M, N, nnz);
+}
+
 /* CSR (r, c) is written as the file entry "c+1 r+1": readCOO's transposition maps it back.
  * The file's matrix is therefore cols x rows (header "cols rows nnz"); square in every reference use. */
 static bspgemm_status write_impl(const char *path, int rows, int cols, const int *rp32,
@@ -154,15 +177,17 @@ static bspgemm_status write_impl(const char *path, int rows, int cols, const int
     if (!path || rows < 0 || cols < 0 || (!rp32 && !rp64)) return BSPGEMM_ERR_INVALID;
     FILE *f = fopen(path, "wb");
     if (!f) return BSPGEMM_ERR_IO;
-    static char big[1 << 20];
-    setvbuf(f, big, _IOFBF, sizeof big);
+    char *big = malloc((size_t)1 << 20);                    /* per call: the writer is re-entrant */
+    if (big) setvbuf(f, big, _IOFBF, (size_t)1 << 20);
     const long long nnz = rp32 ? rp32[rows] - rp32[0] : rp64[rows] - rp64[0];
     fprintf(f, "%%%%MatrixMarket matrix coordinate pattern general\n%d %d %lld\n", cols, rows, nnz);
     for (int r = 0; r < rows; r++) {
         const long long b = rp32 ? rp32[r] : rp64[r], e = rp32 ? rp32[r + 1] : rp64[r + 1];
         for (long long k = b; k < e; k++) fprintf(f, "%d %d\n", col_idx[k] + 1, r + 1);
     }
-    return fclose(f) == 0 ? BSPGEMM_OK : BSPGEMM_ERR_IO;
+    const int rc = fclose(f);
+    free(big);
+    return rc == 0 ? BSPGEMM_OK : BSPGEMM_ERR_IO;
 }
 
 bspgemm_status bspgemm_write_mtx(const char *path, int rows, int cols, const int *row_ptr, const int *col_idx)

@@ -24,7 +24,10 @@
  *
  * With -DBSPGEMM_WITH_MPI: one MPI rank per GPU (rank r -> device r mod #devices), every rank
  * reads the whole file (B replicated, like :309), rows are cut at equal work, C.row_ptr is
- * stitched over RCCL (unique id broadcast with MPI_Bcast); col_idx stays on the GPUs.
+ * stitched by bspgemm_comm_stitch_row_ptr -- one all-gather of int32 row lengths over RCCL (unique
+ * id broadcast with MPI_Bcast), or over MPI_Allgather when the ranks share a GPU (host/
+ * mpi_transport.h); col_idx stays on the GPUs.
+ * BSPGEMM_EXPAND_SYMMETRIC=1 in the environment loads symmetric files expanded (opt-in, f2).
  */
 #include "../../include/bspgemm.h"
 
@@ -33,7 +36,7 @@
 #include <string.h>
 #include <time.h>
 #ifdef BSPGEMM_WITH_MPI
-#include <mpi.h>
+#include "mpi_transport.h"
 #endif
 
 static double now_s(void)
@@ -79,17 +82,19 @@ int main(int argc, char **argv)
     int times = atoi(argv[4]);
     if (times < 1) times = 1;
 
+    const char *sym = getenv("BSPGEMM_EXPAND_SYMMETRIC");
+    const unsigned rflags = (sym && sym[0] == '1') ? BSPGEMM_READ_EXPAND_SYMMETRIC : 0u;
     uint32_t *Arow, *Acol, An, Am, Annz;
-    bspgemm_status st = bspgemm_readCOO(argv[1], &Arow, &Acol, &An, &Am, &Annz);   /* An = M, Am = N */
-    if (st == BSPGEMM_ERR_FORMAT) printf("Could not process Matrix Market banner.\n");   /* utils.c:57 */
-    if (st != BSPGEMM_OK) exit(1);                                                        /* utils.c:55,58,61 */
+    bspgemm_status st = bspgemm_readCOO_ex(argv[1], rflags, &Arow, &Acol, &An, &Am, &Annz);   /* An = M, Am = N */
+    /* the reference prints for a bad banner only (utils.c:56-59); fopen and size-line failures
+     * exit(1) silently (:54-55, :60-61) */
+    if (st == BSPGEMM_ERR_FORMAT) printf("Could not process Matrix Market banner.\n");
+    if (st != BSPGEMM_OK) exit(1);
 
-    int ndev_rank = rank;
+    const int ndev = bspgemm_device_count();
     const char *devenv = getenv("BSPGEMM_DEVICE");
     bspgemm_context *ctx;
-    st = bspgemm_create(devenv ? atoi(devenv) : ndev_rank, &ctx);
-    if (st == BSPGEMM_ERR_INVALID && !devenv) st = bspgemm_create(0, &ctx);   /* fewer devices than ranks */
-    CHECK(st, "bspgemm_create");
+    CHECK(bspgemm_create(devenv ? atoi(devenv) : (ndev > 0 ? rank % ndev : 0), &ctx), "bspgemm_create");
 
     /* in-memory (transposed) shapes: loaded(X) has X.N rows and X.M columns */
     const int a_rows = (int)Am, a_cols = (int)An;
@@ -98,7 +103,7 @@ int main(int argc, char **argv)
     int c_cols = a_cols;
     if (argc >= 6 && strcmp(argv[5], "-") != 0) {
         uint32_t *Brow, *Bcol, Bn, Bm, Bnnz;
-        st = bspgemm_readCOO(argv[5], &Brow, &Bcol, &Bn, &Bm, &Bnnz);
+        st = bspgemm_readCOO_ex(argv[5], rflags, &Brow, &Bcol, &Bn, &Bm, &Bnnz);
         if (st == BSPGEMM_ERR_FORMAT) printf("Could not process Matrix Market banner.\n");
         if (st != BSPGEMM_OK) exit(1);
         if ((int)Bn != a_rows) { fprintf(stderr, "inner dimensions differ: A is %ux%u, B is %ux%u\n", An, Am, Bn, Bm); exit(1); }
@@ -116,12 +121,8 @@ int main(int argc, char **argv)
     bspgemm_comm *comm = NULL;
     const int64_t *d_row_ptr_global = NULL;   /* stitched C.row_ptr, device, owned by comm */
     int64_t *shard_nnz = malloc((size_t)numtasks * sizeof(int64_t));
-    if (numtasks > 1) {
-        unsigned char id[BSPGEMM_UNIQUE_ID_BYTES];
-        if (rank == 0) CHECK(bspgemm_comm_unique_id(id), "unique id");
-        MPI_Bcast(id, BSPGEMM_UNIQUE_ID_BYTES, MPI_BYTE, 0, MPI_COMM_WORLD);
-        CHECK(bspgemm_comm_create(ctx, id, rank, numtasks, &comm), "comm_create");
-    }
+    int used_rccl = 0;
+    if (numtasks > 1) CHECK(mpi_make_comm(ctx, rank, numtasks, devenv ? 1 : ndev, &comm, &used_rccl), "communicator");
 #endif
 
     double *alltimes = malloc((size_t)times * sizeof(double));

@@ -20,6 +20,7 @@
 #ifndef BSPGEMM_H
 #define BSPGEMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -35,8 +36,10 @@ typedef enum bspgemm_status {
     BSPGEMM_ERR_NO_DEVICE = 4,   /* no usable gfx950 device: the product has NO CPU fallback    */
     BSPGEMM_ERR_OVERFLOW  = 5,   /* result does not fit the int32 drop-in interface             */
     BSPGEMM_ERR_IO        = 6,   /* file open / parse failure                                   */
-    BSPGEMM_ERR_FORMAT    = 7,   /* Matrix Market banner / size line rejected                   */
-    BSPGEMM_ERR_COMM      = 8    /* RCCL failure in the multi-GPU exchange                      */
+    BSPGEMM_ERR_FORMAT    = 7,   /* Matrix Market banner rejected                               */
+    BSPGEMM_ERR_COMM      = 8,   /* RCCL failure in the multi-GPU exchange                      */
+    BSPGEMM_ERR_SIZE      = 9    /* Matrix Market size line or an entry rejected (the reference
+                                    exits without a message there, final/utils.c:60-61)         */
 } bspgemm_status;
 
 const char *bspgemm_status_string(bspgemm_status s);
@@ -54,6 +57,7 @@ typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
 typedef struct bspgemm_result  bspgemm_result;    /* device-resident CSR product, int64 row_ptr */
 
+int            bspgemm_device_count(void);       /* visible HIP devices (0 without a GPU)      */
 bspgemm_status bspgemm_create(int device, bspgemm_context **ctx);
 void           bspgemm_destroy(bspgemm_context *ctx);
 /* run on an existing HIP stream (hipStream_t passed as void*; NULL = the context's own) */
@@ -131,20 +135,31 @@ typedef struct bspgemm_stats {
     int64_t products;        /* F                                                            */
     int64_t nnz_c;           /* output nonzeros                                              */
     int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
+    int64_t bytes_read_alg;  /* its HBM-read part: bytes_alg - 4nnzC - 8(rows+1)             */
     int64_t rows_per_bin[BSPGEMM_MAX_BINS]; /* rows per capacity class: [0] empty rows,
                                 [1..bins-2] one-wavefront rows with at most bin_cap[b] products,
                                 [bins-1] heavy rows (one workgroup each); rest unused        */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
-    float   ms_symbolic;     /* row work + scan + binning                                    */
-    float   ms_numeric;      /* accumulate + emit kernels (the dominant kernels)             */
-    float   ms_stitch;       /* count scan + compaction into the final col_idx               */
-    float   ms_bin[BSPGEMM_MAX_BINS];       /* per class: summed duration of its launches    */
-    int     tiles;           /* row super-tiles (each class is launched once per tile)       */
+    float   ms_symbolic;     /* = ms_prepass + ms_count: everything that sizes C.row_ptr     */
+    float   ms_prepass;      /*   row work (products per row) + scan + capacity classes      */
+    float   ms_count;        /*   exact row sizes (hash-set count kernels, heavy rows) + scan */
+    float   ms_numeric;      /* accumulate + emit kernels, rows written at their final place */
+    float   ms_stitch;       /* what is left exposed after them (heavy-row move; masked
+                                product: count scan + compaction)                            */
+    float   ms_bin[BSPGEMM_MAX_BINS];       /* per class: its numeric-phase launch           */
+    float   ms_bin_count[BSPGEMM_MAX_BINS]; /* per class: its symbolic-phase (count) launch  */
+    float   t_bin[BSPGEMM_MAX_BINS];        /* ... and when those launches STARTED, in ms    */
+    float   t_bin_count[BSPGEMM_MAX_BINS];  /*     since the multiply began (the class launches
+                                               alternate over two streams: with the durations
+                                               above this is their timeline)                 */
     int     bins;            /* classes in use, including [0] and the heavy class            */
     int     bin_cap[BSPGEMM_MAX_BINS];      /* products a row of class b may have (masked product:
                                 mask-row length); 0 for [0], INT32_MAX for the heavy class   */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
+/* ... and of earlier ones: age 0 = the last multiply, 1 = the one before, ... up to 15.  The
+ * HIP events of a multiply are its own, so K timed steps can be read back after the timed region. */
+bspgemm_status bspgemm_stats_at(const bspgemm_context *ctx, int age, bspgemm_stats *out);
 
 /* ---------------------------------------------------------------- int32 drop-ins ------
  * Same argument lists and ownership as the reference functions they replace: inputs are host
@@ -195,23 +210,55 @@ typedef struct bspgemm_comm bspgemm_comm;
 bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES]);
 bspgemm_status bspgemm_comm_create(bspgemm_context *ctx, const unsigned char id[BSPGEMM_UNIQUE_ID_BYTES],
                                    int rank, int nranks, bspgemm_comm **comm);
+/* The same stitch over a transport the HOST supplies instead of RCCL -- for ranks that share one
+ * GPU (RCCL refuses two ranks on a device; `mpirun -n 4` on a one-GPU box is how the reference's
+ * `make test` runs, final/Makefile:11-12) and for tests.  Buffers are host memory.  Both
+ * callbacks return 0 on success.  allgather: every rank contributes `bytes` bytes, recv gets
+ * nranks*bytes, rank-major (MPI_Allgather).  gatherv: rank r contributes send_bytes ==
+ * recv_bytes[r]; on `root`, recv gets the concatenation in rank order (MPI_Gatherv, what
+ * final/SpGEMM_mpi_omp.c:203 does with Ccol); may be NULL when bspgemm_comm_gather_col_idx /
+ * SpGEMM_hip_multi are not used.                                                               */
+typedef struct bspgemm_host_transport {
+    void *user;
+    int (*allgather)(void *user, const void *send, void *recv, size_t bytes);
+    int (*gatherv)(void *user, const void *send, size_t send_bytes, void *recv, const size_t *recv_bytes, int root);
+} bspgemm_host_transport;
+bspgemm_status bspgemm_comm_create_host(bspgemm_context *ctx, const bspgemm_host_transport *transport,
+                                        int rank, int nranks, bspgemm_comm **comm);
 void           bspgemm_comm_destroy(bspgemm_comm *comm);
+int            bspgemm_comm_rank(const bspgemm_comm *comm);
+int            bspgemm_comm_size(const bspgemm_comm *comm);
 /* Second half of a stitch whose collective ran elsewhere (bspgemm/dist.py: torch.distributed):
  * `d_lengths` holds the all-gathered int32 row lengths, rank-major, `width` slots per rank of
  * which bounds[r+1]-bounds[r] are used; writes the global int64 row_ptr (bounds[nranks]+1
  * entries) on the device.  Enqueued on `hip_stream` (a hipStream_t; NULL = HIP's default
- * stream) -- pass the stream the collective was issued on; the context's own stream is not used.  Replaces the serial rebase of final/SpGEMM_mpi_omp.c:
- * 213-223.                                                                                    */
+ * stream) -- pass the stream the collective was issued on; the context's own stream is not used.
+ * Replaces the serial rebase of final/SpGEMM_mpi_omp.c:213-223.                               */
 bspgemm_status bspgemm_lengths_to_row_ptr(bspgemm_context *ctx, const int *d_lengths, int nranks, int width,
                                           const int *bounds, int64_t *d_row_ptr, void *hip_stream);
-/* All-gather and rebase: `bounds[nranks+1]` are the shard row bounds every rank used; `local`
- * is this rank's product of rows [bounds[rank],bounds[rank+1]).  On return *d_row_ptr_global
- * points at a device buffer owned by `comm` (bounds[nranks]+1 int64, valid until the next
- * stitch or bspgemm_comm_destroy) holding the stitched global row_ptr on every rank, and
- * shard_nnz[nranks] (host, may be NULL) the per-shard nnz.                                    */
+/* The whole stitch: `bounds[nranks+1]` are the shard row bounds every rank used; `local` is this
+ * rank's product of rows [bounds[rank],bounds[rank+1]).  Every rank contributes its rows' int32
+ * lengths padded to the longest shard, ONE all-gather (RCCL, or the host transport), and
+ * bspgemm_lengths_to_row_ptr on the gathered lengths.  On return *d_row_ptr_global points at a
+ * device buffer owned by `comm` (bounds[nranks]+1 int64, valid until the next stitch or
+ * bspgemm_comm_destroy) holding the global row_ptr on every rank, and shard_nnz[nranks] (host,
+ * may be NULL) the per-shard nnz.  Replaces MPI_Reduce + MPI_Gather + MPI_Gather + the serial
+ * rebase of final/SpGEMM_mpi_omp.c:178-223 (col_idx stays sharded on the GPUs).               */
 bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *comm, const bspgemm_result *local,
                                            const int *bounds, const int64_t **d_row_ptr_global,
                                            int64_t *shard_nnz);
+/* Root gather of the sharded col_idx, the MPI_Gatherv of final/SpGEMM_mpi_omp.c:203: on `root`,
+ * col_idx_host[sum(shard_nnz)] receives the shards in rank order; other ranks pass NULL.
+ * shard_nnz as returned by bspgemm_comm_stitch_row_ptr.  Collective: every rank calls it.      */
+bspgemm_status bspgemm_comm_gather_col_idx(bspgemm_comm *comm, const bspgemm_result *local,
+                                           const int64_t *shard_nnz, int root, int *col_idx_host);
+/* replaces SpGEMM_mpi, final/SpGEMM_mpi_omp.c:155-158: the reference's argument list behind the
+ * communicator it takes implicitly (MPI_COMM_WORLD).  Every rank passes the whole A and B; the
+ * result (*Ccol malloc'ed here, Crow[An+1] caller memory) is valid on rank 0 only (:200-223);
+ * other ranks get *Ccol = NULL.  Collective.  Returns a status like the other drop-ins.        */
+int SpGEMM_hip_multi(bspgemm_comm *comm, int *Acol, int *Arow, int An,
+                     int *Bcol, int *Brow, int Bm,
+                     int **Ccol, int *Crow, int tBlock);
 
 /* ---------------------------------------------------------------- host utilities (C) --
  * Plain C, no GPU needed.                                                                    */
@@ -220,11 +267,19 @@ bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *comm, const bspgemm_res
  * mm_read_mtx_crd_size :189-217 and coo2csc final/coo2csc.c:22-64): Matrix Market pattern
  * file -> CSR of the TRANSPOSED file matrix (the reference's argument swap at utils.c:77),
  * entries kept in file order inside each row, duplicates kept, square assumed (n = M).
- * The reference exit(1)s on failure (silently for fopen, with "Could not process Matrix
- * Market banner." for the banner); this returns BSPGEMM_ERR_IO / _FORMAT so that the CLI can
- * reproduce that behaviour.  Arrays are malloc'd; release with free().                        */
+ * The reference exit(1)s on failure (silently for fopen and for the size line, with "Could not
+ * process Matrix Market banner." for the banner); this returns BSPGEMM_ERR_IO / _SIZE / _FORMAT
+ * so that the CLI can reproduce that behaviour.  Arrays are malloc'd; release with free().     */
 bspgemm_status bspgemm_readCOO(const char *path, uint32_t **row, uint32_t **col,
                                uint32_t *M, uint32_t *N, uint32_t *nnz);
+/* The same loader with options.  flags = 0 is bspgemm_readCOO.  The
+ * reference parses the banner's symmetry token (final/mmio.c:96-179) and then ignores it
+ * (final/utils.c:66-71): BSPGEMM_READ_EXPAND_SYMMETRIC mirrors the stored triangle of a
+ * symmetric / hermitian / skew-symmetric file so that the CSR holds the full pattern (*nnz is
+ * the expanded count).  Off by default: the default result is the reference's, bit for bit.   */
+#define BSPGEMM_READ_EXPAND_SYMMETRIC 1u
+bspgemm_status bspgemm_readCOO_ex(const char *path, unsigned flags, uint32_t **row, uint32_t **col,
+                                  uint32_t *M, uint32_t *N, uint32_t *nnz);
 /* writes a CSR as `%%MatrixMarket matrix coordinate pattern general` such that
  * bspgemm_readCOO (and the reference's readCOO) reconstruct exactly this CSR                  */
 bspgemm_status bspgemm_write_mtx(const char *path, int rows, int cols,

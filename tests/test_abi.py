@@ -69,3 +69,32 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(base, f), errors="replace").read()
                 assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(base, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "bspgemm.h")).read().lower()
+
+
+def test_one_hip_runtime_per_process():
+    """bspgemm first, torch second, in a fresh process: exactly one libamdhip64 may be mapped
+    (round 1's segfault in the RCCL stitch test was two of them: torch's bundled runtime and
+    /opt/rocm's behind libbspgemm.so's rpath -- INTEGRATION.md section 2); and the guard refuses a
+    process that already holds two."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import bspgemm; bspgemm.lib()\n"
+            "import torch\n"
+            "libs = bspgemm.check_single_hip_runtime()\n"
+            "assert len(libs) == 1, libs\n"
+            "print('one runtime:', libs[0])\n") % os.path.join(ROOT, "binary-spgemm_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "one runtime:" in r.stdout
+    bad = ("import ctypes, sys; sys.path.insert(0, %r)\n"
+           "ctypes.CDLL(%r)\n"                      # the library before torch: /opt/rocm's runtime comes with it
+           "import torch\n"
+           "import bspgemm\n"
+           "try:\n"
+           "    bspgemm.check_single_hip_runtime()\n"
+           "except RuntimeError as e:\n"
+           "    print('refused:', e)\n") % (os.path.join(ROOT, "binary-spgemm_amd"),
+                                            os.path.join(ROOT, "binary-spgemm_amd", "libbspgemm.so"))
+    r = subprocess.run([sys.executable, "-c", bad], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "refused: two HIP runtimes" in r.stdout, r.stdout + r.stderr

@@ -42,6 +42,61 @@ def test_bench_driver_usage_and_bad_file(tmp_path):
     assert r.returncode == 1 and "Could not process Matrix Market banner." in r.stdout
     r = _run([os.path.join(PKG, "SpGEMM_hip"), str(tmp_path / "missing.mtx"), "1", "1", "1"])
     assert r.returncode == 1 and r.stdout == ""
+    # a good banner with a bad size line: the reference exits 1 WITHOUT a message (final/utils.c:60-61)
+    bad.write_text("%%MatrixMarket matrix coordinate pattern general\n% a comment\nthree by three\n")
+    for exe, extra in (("SpGEMM_hip", ["1", "1", "1"]), ("SpGEMM_hip_validity", ["1", "1"])):
+        r = _run([os.path.join(PKG, exe), str(bad)] + extra)
+        assert r.returncode == 1 and r.stdout == "", (exe, r.stdout, r.stderr)
+
+
+MPIRUN = "/opt/conda/bin/mpirun"
+
+
+def _mpirun(n, args):
+    env = dict(os.environ, PATH="/opt/conda/bin:" + os.environ.get("PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return _run([MPIRUN, "-n", str(n)] + args, env=env)
+
+
+def _need_mpirun(exe):
+    if not (os.path.exists(exe) and os.path.exists(MPIRUN)):
+        pytest.skip("MPI not available")
+    r = _mpirun(2, ["/bin/true"])
+    if r.returncode != 0:
+        pytest.skip("mpirun cannot start processes on this box: " + r.stderr[-200:])
+
+
+def test_validity_mpi_four_ranks_is_make_test():
+    """the reference's `make test` itself (final/Makefile:11-12): mpirun -n 4 <validity binary>
+    validity_test.mtx 6250 2.  Four ranks on the box's one GPU: SpGEMM_hip_multi over the MPI host
+    transport (equal-work shards, all-gathered row lengths, col_idx gathered on rank 0), compared on
+    rank 0 with the whole product (final/SpGEMM_mpi_omp_validity.c:331-343)."""
+    exe = os.path.join(PKG, "SpGEMM_hip_validity_mpi")
+    _need_mpirun(exe)
+    r = _mpirun(4, [exe, MTX, "6250", "2"])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "Results of serial and multricore are the same!", r.stdout + r.stderr
+    # one rank: the RCCL transport (a communicator of one) runs the same calls
+    r = _mpirun(1, [exe, MTX, "6250", "2"])
+    assert r.returncode == 0 and r.stdout.strip() == "Results of serial and multricore are the same!", r.stdout + r.stderr
+
+
+def test_mpi_driver_three_ranks_host_transport(tmp_path):
+    """the bench driver under mpirun -n 3 on one GPU: three ragged equal-work shards, C.row_ptr
+    stitched through bspgemm_comm_stitch_row_ptr (lengths all-gathered by MPI_Allgather); the total
+    nnz it prints is the product's"""
+    import bspgemm
+    import gen
+    from oracle import oracle as O
+    exe = os.path.join(PKG, "SpGEMM_hip_mpi")
+    _need_mpirun(exe)
+    rp, ci, n = gen.rmat(12, 8, (0.57, 0.19, 0.19, 0.05), seed=77)          # skewed: shards differ in rows
+    p = str(tmp_path / "g.mtx")
+    bspgemm.write_mtx(p, rp, ci)
+    erp, _ = O.spgemm(rp, ci, rp, ci, n)
+    r = _mpirun(3, [exe, p, "64", "1", "2"])
+    assert r.returncode == 0, r.stderr
+    f = r.stdout.strip().split(",")
+    assert f[0] == "3" and int(f[7]) == int(erp[-1]), r.stdout
 
 
 def test_mpi_driver_single_rank():

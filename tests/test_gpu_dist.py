@@ -86,3 +86,134 @@ def test_torch_rccl_stitch_one_rank():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 on ONE GPU: the library's host transport (bspgemm_comm_create_host) lets several "ranks" --
+# here threads of this process, each with its own context and streams; under mpirun, processes that
+# share the GPU -- run the very code an N-GPU job runs around its one all-gather: ragged equal-work
+# shards, padded int32 row lengths, bspgemm_lengths_to_row_ptr, the root gather of col_idx and the
+# SpGEMM_mpi-shaped drop-in.  Only the transport differs from the RCCL job (which needs N devices).
+def _thread_transport(world):
+    import ctypes as C
+    import threading
+    barrier = threading.Barrier(world, timeout=180)
+    slots = [b""] * world
+
+    def make(rank):
+        def allgather(user, send, recv, nbytes):
+            try:
+                slots[rank] = C.string_at(send, nbytes)
+                barrier.wait()
+                data = b"".join(slots)
+                C.memmove(recv, data, len(data))
+                barrier.wait()
+                return 0
+            except Exception:
+                return 1
+
+        def gatherv(user, send, send_bytes, recv, recv_bytes, root):
+            try:
+                slots[rank] = C.string_at(send, send_bytes) if send_bytes else b""
+                barrier.wait()
+                if rank == root:
+                    assert [len(x) for x in slots] == [recv_bytes[r] for r in range(world)]
+                    data = b"".join(slots)
+                    if data:
+                        C.memmove(recv, data, len(data))
+                barrier.wait()
+                return 0
+            except Exception:
+                return 1
+
+        t = bspgemm.HostTransport(None, bspgemm.ALLGATHER_FN(allgather), bspgemm.GATHERV_FN(gatherv))
+        return t
+    return make
+
+
+def _run_ranks(world, body):
+    import threading
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            out[rank] = body(rank)
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errs.append((rank, repr(e)))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_spgemm_hip_multi_host_transport(world):
+    """SpGEMM_hip_multi (the SpGEMM_mpi drop-in, final/SpGEMM_mpi_omp.c:155-225) with `world` ranks on
+    one GPU: rank 0's Crow/Ccol must be the whole product, bit for bit"""
+    import ctypes as C
+    from oracle import oracle as O
+    import gen
+    L = bspgemm.lib()
+    rp, ci, n = gen.rmat(13, 8, (0.57, 0.19, 0.19, 0.05), seed=41)      # skewed: ragged shards, heavy rows
+    erp, eci = O.spgemm(rp, ci, rp, ci, n)
+    rp, ci = bspgemm._i32(rp), bspgemm._i32(ci)
+    make = _thread_transport(world)
+
+    def body(rank):
+        ctx = bspgemm.Context(0)
+        t = make(rank)
+        comm = C.c_void_p()
+        assert L.bspgemm_comm_create_host(ctx._h, C.byref(t), rank, world, C.byref(comm)) == 0, L.bspgemm_last_error()
+        assert L.bspgemm_comm_rank(comm) == rank and L.bspgemm_comm_size(comm) == world
+        crow = np.zeros(n + 1, dtype=np.int32)
+        cc = C.POINTER(C.c_int)()
+        st = L.SpGEMM_hip_multi(comm, ci, rp, n, ci, rp, n, C.byref(cc), crow, 64)
+        assert st == 0, L.bspgemm_last_error()
+        res = None
+        if rank == 0:
+            res = (crow, bspgemm._take_i32(cc, crow[-1]))
+        else:
+            assert not cc, "non-root ranks get *Ccol = NULL (final/SpGEMM_mpi_omp.c:200 allocates on root only)"
+        L.bspgemm_comm_destroy(comm)
+        ctx.close()
+        return res
+    out = _run_ranks(world, body)
+    crow, ccol = out[0]
+    assert np.array_equal(crow, erp) and np.array_equal(ccol, eci)
+
+
+def test_stitch_with_an_empty_shard_host_transport():
+    """bspgemm_comm_stitch_row_ptr on hand-made bounds: a shard of zero rows between two ragged ones;
+    every rank ends with the same global row_ptr, shard_nnz adds up"""
+    import ctypes as C
+    import torch
+    from bspgemm import dist as bdist
+    from oracle import oracle as O
+    L = bspgemm.lib()
+    rp, ci, n = bspgemm.gen_uniform(6000, 6, seed=9)
+    erp, _ = O.spgemm(rp, ci, rp, ci, n)
+    bounds = np.array([0, 4100, 4100, n], dtype=np.int32)
+    world = 3
+    make = _thread_transport(world)
+
+    def body(rank):
+        ctx = bspgemm.Context(0)
+        t = make(rank)
+        comm = C.c_void_p()
+        assert L.bspgemm_comm_create_host(ctx._h, C.byref(t), rank, world, C.byref(comm)) == 0
+        A = ctx.upload(rp, ci, n)
+        Cres = ctx.multiply(A, A, int(bounds[rank]), int(bounds[rank + 1]))
+        dptr = C.c_void_p()
+        shard = np.zeros(world, dtype=np.int64)
+        st = L.bspgemm_comm_stitch_row_ptr(comm, Cres._h, bounds, C.byref(dptr), C.c_void_p(shard.ctypes.data))
+        assert st == 0, L.bspgemm_last_error()
+        g = bdist.device_tensor(dptr.value, n + 1, torch.int64, torch.device("cuda", 0)).cpu().numpy()
+        L.bspgemm_comm_destroy(comm)
+        ctx.close()
+        return g, shard
+    for g, shard in _run_ranks(world, body):
+        assert np.array_equal(g, erp)
+        assert shard.tolist() == [int(erp[4100]), 0, int(erp[n] - erp[4100])]

@@ -214,10 +214,10 @@ def test_fuzz_small_shapes(ctx):
                 h.free()
 
 
-@pytest.mark.parametrize("env", [{"BSPGEMM_TILES": "4"}, {"BSPGEMM_CLASS_STREAMS": "1"}, {"BSPGEMM_CLASS_STREAMS": "3"}],
-                         ids=["row_tiles_4", "one_stream", "three_streams"])
+@pytest.mark.parametrize("env", [{"BSPGEMM_CLASS_STREAMS": "1"}, {"BSPGEMM_CLASS_STREAMS": "3"}],
+                         ids=["one_stream", "three_streams"])
 def test_tuning_knobs_do_not_change_results(ctx, env):
-    """the stream/tile knobs only reorder launches; 300 K rows so that tiles engage"""
+    """the stream knob only reorders launches"""
     rp, ci, n = gen.uniform(300_000, 4, 915)
     erp, eci = O.spgemm(rp, ci, rp, ci, n)
     old = {k: os.environ.get(k) for k in env}
@@ -231,7 +231,6 @@ def test_tuning_knobs_do_not_change_results(ctx, env):
             else:
                 os.environ[k] = v
     assert_same(crp, cci, erp, eci)
-    assert st["tiles"] == int(env.get("BSPGEMM_TILES", 1))
 
 
 def test_mostly_empty_rows(ctx):
@@ -381,6 +380,43 @@ def test_rmat_scale20_properties_and_sampled_rows(ctx):
         erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0, r0 + 4096)
         assert np.array_equal(crp[r0:r0 + 4097] - crp[r0], erp)
         assert np.array_equal(cci[crp[r0]:crp[r0 + 4096]], eci)
+
+
+def test_baseline_cfg3_rmat_scale22_full_size(ctx):
+    """BASELINE config 3 -- the matrix bench.py times (R-MAT scale 22, edge factor 16, mild skew, A*A,
+    nnz(C) = 1.336 G) -- at FULL size, checked completely: well-formedness on the device, product
+    count against the oracle, then row_ptr and all 1.3 G column indices against the oracle's
+    OpenMP restatement of SpGEMM_omp (final/SpGEMM_mpi_omp.c:71-143) run on the host cores."""
+    import torch
+    from bspgemm import dist as bdist
+    dev = torch.device("cuda", 0)
+    rp, ci, n = bspgemm.gen_rmat(22, 16, (0.30, 0.25, 0.25), seed=1)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A)
+    st = ctx.stats()
+    crp, _ = C.download(col_idx=False)
+    assert st["products"] == O.count_products(rp, ci, rp) == 1336443900
+    assert C.nnz == crp[-1] == st["nnz_c"] == 1336366087          # the number bench.py prints
+    assert crp[0] == 0 and np.all(np.diff(crp) >= 0)
+    cols = bdist.device_tensor(C.col_idx_device, C.nnz, torch.int32, dev)
+    assert int(cols.min()) >= 0 and int(cols.max()) < n
+    bad = (cols[1:] <= cols[:-1])                                   # not ascending ... unless a new row starts there
+    starts = torch.from_numpy(crp[1:-1][(crp[1:-1] > 0) & (crp[1:-1] < C.nnz)]).to(dev)
+    bad[starts - 1] = False
+    assert not bool(bad.any()), "col_idx must be strictly ascending inside every row"
+    del bad, starts
+    # blocks of 4096 rows, exact (cheap, and they localise a failure before the full comparison)
+    for r0 in (0, 1000, n // 2, n - 4096):
+        erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0, r0 + 4096)
+        assert np.array_equal(crp[r0:r0 + 4097] - crp[r0], erp)
+        assert np.array_equal(cols[int(crp[r0]): int(crp[r0 + 4096])].cpu().numpy(), eci)
+    del cols
+    # everything
+    _, cci = C.download()
+    C.free()
+    erp, eci = O.spgemm_omp(rp, ci, rp, ci, n, 4096, 0)
+    assert np.array_equal(crp, erp)
+    assert np.array_equal(cci, eci)
 
 
 def _sampled_rows_exact(rp, ci, n, crp, col_tensor, starts, block=64):

@@ -22,7 +22,8 @@ def test_readcoo_matches_reference_goldens():
 
 
 def test_readcoo_error_behaviour(tmp_path):
-    """reference: fopen failure -> exit(1) (utils.c:54), bad banner -> message + exit(1) (:56-59)"""
+    """reference: fopen failure -> exit(1) (utils.c:54), bad banner -> message + exit(1) (:56-59),
+    bad size line -> exit(1) WITHOUT a message (:60-61): a status of its own, so the CLI can tell"""
     with pytest.raises(bspgemm.BspgemmError) as e:
         bspgemm.readCOO(str(tmp_path / "nope.mtx"))
     assert e.value.status == 6
@@ -34,7 +35,39 @@ def test_readcoo_error_behaviour(tmp_path):
     p.write_text("%%MatrixMarket matrix coordinate pattern general\n% only comments\n")
     with pytest.raises(bspgemm.BspgemmError) as e:
         bspgemm.readCOO(str(p))
-    assert e.value.status == 7
+    assert e.value.status == 9
+    p.write_text("%%MatrixMarket matrix coordinate pattern general\n2 2 x\n")
+    with pytest.raises(bspgemm.BspgemmError) as e:
+        bspgemm.readCOO(str(p))
+    assert e.value.status == 9
+
+
+def test_readcoo_symmetric_expansion_is_opt_in(tmp_path):
+    """f2: the reference parses the symmetry token (mmio.c:96-179) and ignores it (utils.c:66-71);
+    the default stays reference-exact, BSPGEMM_READ_EXPAND_SYMMETRIC mirrors the stored triangle"""
+    p = tmp_path / "s.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n4 4 4\n1 1\n3 1\n4 2\n4 4\n")
+    rp, ci, m, n = bspgemm.readCOO(str(p))
+    orp, oci, _, _ = O.read_mtx(str(p))                       # oracle = reference semantics: not expanded
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and rp[-1] == 4
+    rp2, ci2, m2, n2 = bspgemm.readCOO(str(p), expand_symmetric=True)
+    assert (m2, n2) == (4, 4) and rp2[-1] == 6
+    import scipy.sparse as sp
+    full = sp.csr_matrix((np.ones(6), ci2, rp2), shape=(4, 4)).toarray() > 0
+    want = np.zeros((4, 4), bool)
+    for i, j in ((0, 0), (2, 0), (3, 1), (3, 3)):
+        want[i, j] = want[j, i] = True
+    assert np.array_equal(full, want)                           # symmetric: the transpose quirk is invisible
+    # a general file is untouched by the flag; a real symmetric file has its values skipped
+    g = tmp_path / "g.mtx"
+    g.write_text("%%MatrixMarket matrix coordinate pattern general\n3 3 2\n2 1\n3 2\n")
+    a = bspgemm.readCOO(str(g))
+    b = bspgemm.readCOO(str(g), expand_symmetric=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    r = tmp_path / "r.mtx"
+    r.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 2\n2 1 0.5\n3 3 2.0\n")
+    rp3, ci3, _, _ = bspgemm.readCOO(str(r), expand_symmetric=True)
+    assert rp3.tolist() == [0, 1, 2, 3] and ci3.tolist() == [1, 0, 2]
 
 
 def test_readcoo_transposes_and_keeps_file_order(tmp_path):
