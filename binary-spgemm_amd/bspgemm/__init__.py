@@ -51,6 +51,7 @@ EXPORTS = [
     "bspgemm_matrix_from_result", "bspgemm_closure",
     "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
     "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
+    "bspgemm_set_flow",
 ]
 
 
@@ -144,6 +145,7 @@ def lib():
     L.bspgemm_destroy.restype = None
     L.bspgemm_set_stream.argtypes = [VP, VP]
     L.bspgemm_synchronize.argtypes = [VP]
+    L.bspgemm_set_flow.argtypes = [VP, C.c_int]
     L.bspgemm_matrix_upload.argtypes = [VP, C.c_int, C.c_int, VP, VP, PVP]
     L.bspgemm_matrix_wrap_device.argtypes = [VP, C.c_int, C.c_int, C.c_int64, VP, VP, PVP]
     L.bspgemm_matrix_free.argtypes = [VP]
@@ -317,6 +319,10 @@ class Context:
 
     def synchronize(self):
         _chk(lib().bspgemm_synchronize(self._h), "synchronize")
+
+    def set_flow(self, flow):
+        """"auto" | "upper-bound" | "exact" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
+        _chk(lib().bspgemm_set_flow(self._h, {"auto": 0, "upper-bound": 1, "exact": 2}[flow]), "set_flow")
 
     def upload(self, row_ptr, col_idx, cols, row0=0, rows=None):
         """Host CSR -> device.  row0/rows select an interior row range (absolute row_ptr values)."""

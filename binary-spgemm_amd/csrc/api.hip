@@ -128,6 +128,7 @@ struct bspgemm_context {
     struct CachedBuf { void *p; size_t bytes; };
     CachedBuf cache[8] = {};
     size_t cache_budget = 0;            // bytes the cache may pin (a quarter of the device memory)
+    int flow = BSPGEMM_FLOW_AUTO;       // bspgemm_set_flow / BSPGEMM_FLOW
 };
 
 extern "C" int bspgemm_par_max_plus_one(const int *idx, long long n);              // host/par_copy.c
@@ -139,7 +140,20 @@ struct bspgemm_matrix {
     long long nnz;
     int *d_row_ptr, *d_col_idx;
     bool owned;
+    // row lengths clamped to 255, one byte per row: what a product with this matrix as B gathers
+    // per A-nonzero to size its rows (csrc/prepass.hip: k_row_products).  Part of the operand's
+    // device layout: built when the operand is created (lazily for wrapped device arrays).
+    mutable unsigned char *d_deg8 = nullptr;
 };
+
+static bspgemm_status ensure_deg8(const bspgemm_matrix *m)
+{
+    if (m->d_deg8) return BSPGEMM_OK;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_deg8), (size_t)m->rows + 1));
+    launch_deg8(m->d_row_ptr, m->rows, m->d_deg8, m->ctx->stream);
+    HIPCHK(hipGetLastError());
+    return BSPGEMM_OK;
+}
 
 struct bspgemm_result {
     bspgemm_context *ctx;
@@ -195,6 +209,9 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (auto &t : ctx->ev_tile) for (auto &e : t) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->cache_budget = prop.totalGlobalMem / 4;
+    if (const char *e = getenv("BSPGEMM_FLOW"))
+        ctx->flow = !strcmp(e, "exact") ? BSPGEMM_FLOW_EXACT : (!strcmp(e, "upper-bound") || !strcmp(e, "ub")) ? BSPGEMM_FLOW_UPPER_BOUND
+                                                                                                               : BSPGEMM_FLOW_AUTO;
     if (getenv("BSPGEMM_DEBUG_ALLOC"))
         fprintf(stderr, "[bspgemm] device %d: %s, %zu MiB, %d CUs; result cache budget %zu MiB\n", device,
                 prop.gcnArchName, (size_t)(prop.totalGlobalMem >> 20), prop.multiProcessorCount, ctx->cache_budget >> 20);
@@ -270,6 +287,7 @@ extern "C" bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, 
     if (nnz > 0)
         HIPCHK_B(hipMemcpyAsync(m->d_col_idx, col_idx + base, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     launch_rebase_i32(m->d_row_ptr, rows + 1, (int)base, ctx->stream);
+    if (bspgemm_status st = ensure_deg8(m)) return bail(st);
     HIPCHK_B(hipStreamSynchronize(ctx->stream));
     *out = m;
     return BSPGEMM_OK;
@@ -291,11 +309,12 @@ extern "C" bspgemm_status bspgemm_matrix_wrap_device(bspgemm_context *ctx, int r
 extern "C" void bspgemm_matrix_free(bspgemm_matrix *m)
 {
     if (!m) return;
+    hipSetDevice(m->ctx->device);
     if (m->owned) {
-        hipSetDevice(m->ctx->device);
         hipFree(m->d_row_ptr);
         hipFree(m->d_col_idx);
     }
+    hipFree(m->d_deg8);
     delete m;
 }
 extern "C" int bspgemm_matrix_rows(const bspgemm_matrix *m) { return m ? m->rows : 0; }
@@ -504,7 +523,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
 // nnz(C) entries) -- the two passes BASELINE.json's north star names.  Heavy rows (F_i > 2048) are
 // accumulated and read out once, during the symbolic phase, into a workspace bounded by
 // sum(min(F_i, cols)), and moved to their place during the numeric phase.
-static bspgemm_status multiply_plain(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
+static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
                                      int row_begin, int row_end, bspgemm_result **out)
 {
     if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
@@ -529,7 +548,8 @@ static bspgemm_status multiply_plain(bspgemm_context *ctx, const bspgemm_matrix 
     // ---- symbolic 1: per-row products, their prefix, capacity classes ---------------------
     const int scan_tiles = (R + 2047) / 2048;
     const int heavy_cols = B->cols > 0 ? B->cols : 1;
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
+    if (bspgemm_status st = ensure_deg8(B)) return bail(st);       // (wrapped device arrays: first use)
+    launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, row_begin, row_end, ctx->F, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, s);
     HostScalars *h = ctx->h;
@@ -574,11 +594,14 @@ static bspgemm_status multiply_plain(bspgemm_context *ctx, const bspgemm_matrix 
             hipStream_t sx = lanes[pos % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b];
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
-            if (b <= kWaveBins)
-                launch_wave_count(b, ctx->ab, B->d_col_idx, B->cols, rec, n, row_begin, ctx->cnt, sx);
-            else
+            if (b <= kWaveBins) {
+                launch_wave_count(b, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols, ctx->ab, rec, n, row_begin,
+                                  ctx->cnt, sx);
+            } else {
+                launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
                 HIPCHK_B(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
+            }
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
         }
         HIPCHK_B(hipGetLastError());
@@ -643,14 +666,14 @@ static bspgemm_status multiply_plain(bspgemm_context *ctx, const bspgemm_matrix 
 // C = F .* (A*B).  The mask bounds a row (|C_i| <= |F_i|), usually far below its product count, so
 // rows are binned and placed by MASK length in an upper-bound workspace and squeezed together by
 // the compaction kernel once the counts are scanned.
-static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_matrix *A,
+static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_matrix *A,
                                            const bspgemm_matrix *B, const bspgemm_matrix *Fm,
                                            int row_begin, int row_end, bspgemm_result **out)
 {
     if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
     *out = nullptr;
     if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
-    if (Fm->ctx != ctx || Fm->rows < row_end) return FAIL(BSPGEMM_ERR_INVALID, "mask has fewer rows than A / wrong context");
+    if (Fm && (Fm->ctx != ctx || Fm->rows < row_end)) return FAIL(BSPGEMM_ERR_INVALID, "mask has fewer rows than A / wrong context");
     if (bspgemm_status st = use_device(ctx)) return st;
     const int R = row_end - row_begin;
     hipStream_t s = ctx->stream, sB = ctx->stream_b, sC = ctx->stream_c;
@@ -669,11 +692,15 @@ static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_m
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
     HostScalars *h = ctx->h;
     h->products = 0;
-    launch_sum_i64(ctx->F, R, ctx->partials, s);
-    HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
-                            hipMemcpyDeviceToHost, s));
-    launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
-    launch_scan_and_bin(ctx->Fmask, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+    const long long *size_by = ctx->F;          // what rows are binned and placed by: products ...
+    if (Fm) {                                   // ... or, masked, the mask row's length (|C_i| <= |F_i|)
+        launch_sum_i64(ctx->F, R, ctx->partials, s);
+        HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
+                                hipMemcpyDeviceToHost, s));
+        launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
+        size_by = ctx->Fmask;
+    }
+    launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, s);
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -682,11 +709,16 @@ static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_B(hipEventRecord(slot.ev[1], s));
     HIPCHK_B(hipEventRecord(slot.ev[2], s));               // no separate count phase here
     HIPCHK_B(hipStreamSynchronize(s));
-    const long long total = R > 0 ? h->totalF : 0;         // sum of the mask-row lengths: bounds nnz(C)
+    const long long total = R > 0 ? h->totalF : 0;         // products (masked: sum of mask-row lengths): bounds nnz(C)
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
     if (bspgemm_status st = ensure_tmp(ctx, (size_t)total + 1)) return bail(st);
-    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(total)));
-    C->col_cap = total;
+    // C.col_idx: a cached buffer of the upper-bound size is taken now (nothing to wait for); else it
+    // is allocated with exactly nnz(C) entries once the counts are scanned
+    if (result_cached(ctx, result_bytes_colidx(total))) {
+        HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(total)));
+        C->col_cap = total;
+    }
+    const int levels = wave_levels_for_cols(B->cols);
 
     size_t bin_start[kNumBins + 1] = {0, 0};
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
@@ -705,7 +737,13 @@ static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_m
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
             HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
-            if (b <= kWaveBins && wave_masked_supported(B->cols))
+            if (!Fm && b <= kWaveBins)
+                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
+                                 ctx->tmp, ctx->cnt, sx);
+            else if (!Fm)
+                HIPCHK_B(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
+                                           ctx->cnt, sx));
+            else if (b <= kWaveBins && wave_masked_supported(B->cols))
                 launch_wave_masked(b, ctx->ab, B->d_col_idx, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
                                    row_begin, ctx->tmp, ctx->cnt, sx);
             else
@@ -720,17 +758,25 @@ static bspgemm_status multiply_masked_impl(bspgemm_context *ctx, const bspgemm_m
         }
         HIPCHK_B(hipEventRecord(slot.ev[3], s));
         launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, nullptr, s);
-        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, 0, R, total, C->d_col_idx, s);
-        HIPCHK_B(hipGetLastError());
     } else {
         HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
         HIPCHK_B(hipEventRecord(slot.ev[3], s));
     }
     HIPCHK_B(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    if (!C->d_col_idx) {
+        HIPCHK_B(hipStreamSynchronize(s));
+        const long long want = (total - h->nnzC <= h->nnzC / 50 + 4096) ? total : h->nnzC;
+        HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(want)));
+        C->col_cap = want;
+    }
+    if (R > 0) {
+        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, 0, R, total, C->d_col_idx, s);
+        HIPCHK_B(hipGetLastError());
+    }
     HIPCHK_B(hipEventRecord(slot.ev[4], s));
     HIPCHK_B(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, R > 0 ? h->products : 0, C->nnz, cls_n);
+    close_slot(ctx, R, h, (Fm && R > 0) ? h->products : total, C->nnz, cls_n);
     *out = C;
     return BSPGEMM_OK;
 }
@@ -739,7 +785,27 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
                                            const bspgemm_matrix *B, int row_begin, int row_end,
                                            bspgemm_result **out)
 {
-    return multiply_plain(ctx, A, B, row_begin, row_end, out);
+    // Two ways to the same CSR (tuning): "exact" sizes every row first (symbolic
+    // count pass) and emits at the final place: C.col_idx is nnz(C) entries and there is no workspace
+    // of F entries; "upper-bound" places rows by their product count and squeezes them together
+    // afterwards: faster where duplicates are rare (the compaction streams at HBM rate, the count
+    // pass costs most of a numeric pass), but it holds 2F entries.  Default: upper-bound, and exact
+    // when that does not fit.
+    if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
+    if (ctx->flow == BSPGEMM_FLOW_EXACT) return multiply_exact(ctx, A, B, row_begin, row_end, out);
+    bspgemm_status st = multiply_upper_bound(ctx, A, B, nullptr, row_begin, row_end, out);
+    if (st == BSPGEMM_ERR_ALLOC && ctx->flow == BSPGEMM_FLOW_AUTO) {
+        (void)hipGetLastError();
+        st = multiply_exact(ctx, A, B, row_begin, row_end, out);
+    }
+    return st;
+}
+
+extern "C" bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow)
+{
+    if (!ctx || flow < BSPGEMM_FLOW_AUTO || flow > BSPGEMM_FLOW_EXACT) return FAIL(BSPGEMM_ERR_INVALID, "set_flow");
+    ctx->flow = flow;
+    return BSPGEMM_OK;
 }
 
 extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx, const bspgemm_matrix *A,
@@ -750,7 +816,7 @@ extern "C" bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx, const bs
         if (out) *out = nullptr;
         return FAIL(BSPGEMM_ERR_INVALID, "mask is NULL");
     }
-    return multiply_masked_impl(ctx, A, B, F, row_begin, row_end, out);
+    return multiply_upper_bound(ctx, A, B, F, row_begin, row_end, out);
 }
 
 extern "C" int bspgemm_result_rows(const bspgemm_result *C) { return C ? C->rows : 0; }
@@ -843,6 +909,7 @@ extern "C" bspgemm_status bspgemm_matrix_from_result(bspgemm_context *ctx, const
     launch_narrow_row_ptr(C->d_row_ptr, m->d_row_ptr, C->rows + 1, ctx->stream);
     if (C->nnz > 0)
         HIPCHK_B(hipMemcpyAsync(m->d_col_idx, C->d_col_idx, (size_t)C->nnz * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    if (bspgemm_status st = ensure_deg8(m)) return bail(st);
     HIPCHK_B(hipStreamSynchronize(ctx->stream));
     *out = m;
     return BSPGEMM_OK;
@@ -865,6 +932,7 @@ extern "C" bspgemm_status bspgemm_closure(bspgemm_context *ctx, const bspgemm_ma
         HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&cur->d_row_ptr), ((size_t)n + 1) * sizeof(int)));
         HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&cur->d_col_idx), ((size_t)cur->nnz + 1) * sizeof(int)));
         launch_add_diagonal(A->d_row_ptr, A->d_col_idx, n, cur->d_row_ptr, cur->d_col_idx, ctx->stream);
+        if (bspgemm_status st = ensure_deg8(cur)) return bail(st);
         HIPCHK_B(hipStreamSynchronize(ctx->stream));
     }
     long long prev_nnz = -1;      // nnz of the deduplicated T(k); unknown for T0 (may hold duplicates)
@@ -901,8 +969,8 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = use_device(ctx)) return st;
     const int R = A->rows;
     if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
-    if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, 0, R, ctx->F, ctx->ab, ctx->stream);
+    if (bspgemm_status st = ensure_deg8(B)) return st;
+    launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, 0, R, ctx->F, ctx->stream);
     launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
                         ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));

@@ -67,6 +67,14 @@ struct RowRec {
 void launch_row_work(const int *Arow, const int *Acol, const int *Brow,
                      int row_begin, int row_end, long long *F, int2 *ab, hipStream_t s);
 
+// deg8[i] = min(|row i|, 255): the per-operand byte table behind launch_row_products
+void launch_deg8(const int *row_ptr, int n, unsigned char *deg8, hipStream_t s);
+// F only (no extents), through B's byte table of row lengths
+void launch_row_products(const int *Arow, const int *Acol, const int *Brow, const unsigned char *Bdeg8,
+                         int row_begin, int row_end, long long *F, hipStream_t s);
+// extents of the listed rows' A-nonzeros (heavy rows of a plain product)
+void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const int *Brow, int2 *ab, hipStream_t s);
+
 // exclusive scan of F (int64) into prefix[0..n] and, fused, classification of every row into
 // the capacity classes: rec[] holds the non-empty rows grouped by class (class b starts at
 // sum(bin_count[1..b-1])), recpre[] their output offsets; bin_count[8] on the device.
@@ -81,9 +89,10 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
                         const long long *base, hipStream_t s);
 
-// symbolic phase, one wave per row: cnt[row] = |C_row| exactly (hash set in LDS, nothing emitted)
-void launch_wave_count(int bin, const int2 *ab, const int *Bcol, int cols, const RowRec *rec, int nrows,
-                       int row_begin, int *cnt, hipStream_t s);
+// symbolic phase, one wave per row: gathers the row's B-row extents (left in ab[] for the numeric
+// phase), then cnt[row] = |C_row| exactly (hash set in LDS, nothing emitted)
+void launch_wave_count(int bin, const int *Acol, const int *Brow, const int *Bcol, int cols, int2 *ab,
+                       const RowRec *rec, int nrows, int row_begin, int *cnt, hipStream_t s);
 
 // numeric phase, one wave per row (rank-bitmap accumulator).  row_ptr != NULL: row i is written at
 // tmp + row_ptr[i - row_begin] (tmp = C.col_idx, sizes known from the symbolic phase, cnt may be

@@ -80,6 +80,89 @@ void launch_row_work(const int *Arow, const int *Acol, const int *Brow,
 }
 
 // ---------------------------------------------------------------------------------------
+// Products per row WITHOUT the extents: the plain product only needs F_i here (capacity classes,
+// shard cuts); its count kernels gather the B-row extents themselves, hidden behind their hashing
+// (wave_count.hip).  What is gathered per A-nonzero is ONE BYTE from a table that fits an XCD's
+// L2 for matrices up to ~4 M rows -- B's row lengths clamped to 255, built once per operand --
+// instead of an 8-byte B.row_ptr pair out of a table four to eight times the L2 (the pair gather
+// is what bounds k_row_work: one 64-byte sector fetched per nonzero).  A clamped entry (a B row
+// of 255 or more) is looked up exactly.
+__global__ __launch_bounds__(256) void k_deg8(const int *__restrict__ row_ptr, int n, unsigned char *__restrict__ deg8)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int d = row_ptr[i + 1] - row_ptr[i];
+        deg8[i] = (unsigned char)(d < 255 ? d : 255);
+    }
+}
+void launch_deg8(const int *row_ptr, int n, unsigned char *deg8, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_deg8, dim3((n + 255) / 256), dim3(256), 0, s, row_ptr, n, deg8);
+}
+
+__global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ Arow, const int *__restrict__ Acol,
+                                                      const int *__restrict__ Brow,
+                                                      const unsigned char *__restrict__ Bdeg8,
+                                                      int row_begin, int nrows, long long *__restrict__ F)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(gid >> 3);
+    const int sub = (int)(gid & 7);
+    long long sum = 0;
+    if (r < nrows) {
+        const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
+        constexpr int U = 4;                                       // independent gathers in flight per lane
+        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {
+            int j[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            int d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) d[u] = j[u] >= 0 ? (int)Bdeg8[j[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (d[u] == 255) d[u] = Brow[j[u] + 1] - Brow[j[u]];   // clamped: the exact length (rare)
+                sum += (long long)d[u];
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    if (r < nrows && sub == 0) F[r] = sum;
+}
+
+void launch_row_products(const int *Arow, const int *Acol, const int *Brow, const unsigned char *Bdeg8,
+                         int row_begin, int row_end, long long *F, hipStream_t s)
+{
+    const int nrows = row_end - row_begin;
+    if (nrows <= 0) return;
+    const long long threads = (long long)nrows * 8;
+    hipLaunchKernelGGL(k_row_products, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, Arow, Acol, Brow, Bdeg8,
+                       row_begin, nrows, F);
+}
+
+// ab[jj] = (B.row_ptr[A.col_idx[jj]], |B_j|) for the A-nonzeros of the listed rows only (the heavy
+// rows of a plain product: their kernel wants the extents like everybody else, but no count kernel
+// has passed over them).  One workgroup per row.
+__global__ __launch_bounds__(256) void k_extents_of_rows(const RowRec *__restrict__ rec, const int *__restrict__ Acol,
+                                                         const int *__restrict__ Brow, int2 *__restrict__ ab)
+{
+    const RowRec q = rec[blockIdx.x];
+    for (int t = threadIdx.x; t < q.alen; t += 256) {
+        const int j = Acol[q.a0 + t];
+        const int b0 = Brow[j];
+        ab[q.a0 + t] = make_int2(b0, Brow[j + 1] - b0);
+    }
+}
+void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const int *Brow, int2 *ab, hipStream_t s)
+{
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_extents_of_rows, dim3(nrows), dim3(256), 0, s, rec, Acol, Brow, ab);
+}
+
+// ---------------------------------------------------------------------------------------
 // Exclusive scan in three kernels: tile sums -> scan of the tile sums -> apply.
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;

@@ -64,10 +64,12 @@ __device__ __forceinline__ u32 hash_slot(u32 col)
     return m >> (32 - LOGH);
 }
 
+struct __attribute__((packed, aligned(4))) Int2U { int x, y; };   // 8 B, only dword aligned
+
 template <int CHUNKS, bool WIDE>
 __global__ __launch_bounds__((64 * CountCfg<CHUNKS>::WAVES))
-void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
-                  const RowRec *__restrict__ rec, int nrows, int rpw, int row_begin,
+void k_wave_count(const int *__restrict__ Acol, const int *__restrict__ Brow, const int *__restrict__ Bcol,
+                  int2 *__restrict__ ab, const RowRec *__restrict__ rec, int nrows, int rpw, int row_begin,
                   int *__restrict__ cnt)
 {
     using Cfg = CountCfg<CHUNKS>;
@@ -98,18 +100,31 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
     if (lane < CHUNKS) starts[lane] = 0ull;
     wave_lds_fence();
 
-    // Software pipeline over the rows of this wave: while row k goes through the hash set, the
-    // B.col_idx gather of row k+1 is already in flight (its plan -- extents, starts bitmap, source
-    // offsets -- is made first; delta[] is free again once the gather addresses are in registers)
-    // and the extents of row k+2 are being prefetched.
-    int2 ab_next = make_int2(0, 0);
-    auto prefetch_extents = [&](int k) {
-        ab_next = make_int2(0, 0);
+    // Software pipeline over the rows of this wave, three rows deep.  While row k goes through the
+    // hash set:  the B.col_idx gather of row k+1 is in flight (its plan -- extents, starts bitmap,
+    // source offsets -- is made first; delta[] is free again once the gather addresses are in
+    // registers);  the B.row_ptr pairs of row k+2's A-nonzeros are being gathered (one 8-byte random
+    // access each: what the prepass kernel of the masked product spends its whole time on is hidden
+    // here);  and the A.col_idx of row k+3 is being read.  The extents are left in ab[] for the
+    // numeric pass, which then reads them coalesced.
+    int acol_next = -1;                                            // A.col_idx of the row after next, one per lane
+    int2 ab_next = make_int2(0, 0);                                // (B.row_ptr[j], |B_j|) of the next row
+    auto load_acol = [&](int k) {
+        acol_next = -1;
         if (k < nmine) {
             const int na0 = wave_bcast(r_a0, k), nalen = wave_bcast(r_alen, k);
-            if (lane < nalen) ab_next = ab[na0 + lane];
+            if (lane < nalen) acol_next = Acol[na0 + lane];
         }
     };
+    auto extent_of = [&](int j) {
+        int2 e = make_int2(0, 0);
+        if (j >= 0) {
+            const Int2U pr = *reinterpret_cast<const Int2U *>(Brow + j);   // one 8-B gather (dword aligned)
+            e = make_int2(pr.x, pr.y - pr.x);
+        }
+        return e;
+    };
+    auto prefetch_extents = [&]() { ab_next = extent_of(acol_next); };
     u32 coln[CHUNKS];                                              // products of the NEXT row, in flight
     int Fn = 0;
     auto issue_gather = [&](int k) {                               // wave-uniform k < nmine
@@ -119,18 +134,20 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
         int F = 0, nsrc = 0;
         for (int ab0 = 0; ab0 < alen; ab0 += 64) {
             int2 e = ab_next;
-            if (ab0 > 0) {
-                e = make_int2(0, 0);
-                if (ab0 + lane < alen) e = ab[a0 + ab0 + lane];
-            }
+            if (ab0 > 0)                                           // a row with more than 64 A-nonzeros (rare)
+                e = extent_of(ab0 + lane < alen ? Acol[a0 + ab0 + lane] : -1);
+            if (ab0 + lane < alen) ab[a0 + ab0 + lane] = e;        // for the numeric pass
             const int bs = e.x, len = e.y;
             const int inc = wave_incl_scan(len);
             const int excl = F + inc - len;
-            const u64 bal = __ballot(len > 0);
+            const u64 bal = __builtin_amdgcn_ballot_w64(len > 0);
             if (len > 0) {
-                const int sidx = nsrc + __popcll(bal & mask_lt(lane));
+                // sources are marked at their LAST product: the source of product p is then simply
+                // the number of marks before p (mbcnt), no own-bit correction
+                const int sidx = (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, (u32)nsrc));
+                const int last = excl + len - 1;
                 delta[sidx] = bs - excl;
-                atomicOr(&starts[excl >> 6], 1ull << (excl & 63));
+                atomicOr(&starts[last >> 6], 1ull << (last & 63));
             }
             F += wave_bcast(inc, 63);
             nsrc += __popcll(bal);
@@ -146,7 +163,7 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
             const int p = c * 64 + lane;
             const u64 M = wave_bcast64(sw, c);
             const int before = wave_bcast(sbefore, c);
-            int s = before + __popcll(M & mask_le(lane)) - 1;
+            int s = (int)__builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, (u32)before));
             s = p < F ? s : 0;
             gaddr[c] = delta[s];
         }
@@ -158,9 +175,12 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
         Fn = F;
         wave_lds_fence();   // delta is dead from here on (its reads have been consumed by the loads above)
     };
-    prefetch_extents(0);
+    load_acol(0);
+    prefetch_extents();                                            // row 0
+    load_acol(1);
     issue_gather(0);
-    prefetch_extents(1);
+    prefetch_extents();                                            // row 1
+    load_acol(2);
 
     int my_cnt = 0;
     for (int kk = 0; kk < nmine; kk++) {
@@ -170,7 +190,8 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
         const int F = Fn;
         if (kk + 1 < nmine) {                                      // uniform
             issue_gather(kk + 1);
-            prefetch_extents(kk + 2);
+            prefetch_extents();                                    // row kk + 2
+            load_acol(kk + 3);
         }
 
         // ---- hash set, first probe of every product: straight-line, all chunks in flight -----
@@ -187,17 +208,16 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
         // its column (a duplicate: what `if (!xb[k])` skips at :38).  The others -- the slot holds
         // another column -- are squeezed together in LDS and probe on, one instruction per round for
         // all of them instead of one per chunk.
-        int fresh = 0;                                             // per lane: new columns it stored
+        int fresh = 0;                                             // wave-uniform: new columns stored so far
         int nuns = 0;
 #pragma unroll
         for (int c = 0; c < CHUNKS; c++) {
-            fresh += (old[c] == kEmptySlot) ? 1 : 0;
-            const bool uns = old[c] != kEmptySlot && old[c] != col[c];
-            const u64 ub = __ballot(uns);
-            if (ub) {                                              // uniform
-                if (uns) unsettled[nuns + __popcll(ub & mask_lt(lane))] = col[c];
-                nuns += __popcll(ub);
-            }
+            const u64 fb = __builtin_amdgcn_ballot_w64(old[c] == kEmptySlot);
+            const u64 ub = __builtin_amdgcn_ballot_w64(old[c] != col[c]) & ~fb;
+            fresh += __popcll(fb);
+            if ((ub >> lane) & 1ull)
+                unsettled[__builtin_amdgcn_mbcnt_hi((u32)(ub >> 32), __builtin_amdgcn_mbcnt_lo((u32)ub, (u32)nuns))] = col[c];
+            nuns += __popcll(ub);
         }
         wave_lds_fence();
         u32 *slot0 = nullptr;                                      // last slot touched by this lane's key of batch 0
@@ -212,15 +232,13 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
                     hs = (hs + 1u) & (u32)(H - 1);
                     o = atomicCAS(&tab[hs], kEmptySlot, key);
                 }
-                fresh += (o == kEmptySlot) ? 1 : 0;
+                fresh += __popcll(__builtin_amdgcn_ballot_w64(o == kEmptySlot));
                 go = go && o != kEmptySlot && o != key;
             }
             if (b0 == 0) slot0 = have ? tab + hs : nullptr;
             else if (have) unsettled[b0 + lane] = hs;              // remembered for the wipe (the key is done)
         }
-        // |C_i| = new columns over all lanes
-        const int total = wave_bcast(wave_incl_scan(fresh), 63);
-        my_cnt = (lane == kk) ? total : my_cnt;                    // lane kk keeps |C_i| of row kk
+        my_cnt = (lane == kk) ? fresh : my_cnt;                    // |C_i| = new columns; lane kk keeps row kk's
         // ---- wipe every slot this row touched (the reference's sparse reset, :48-50).  Touched but
         // not filled by this lane (a duplicate's, or another column's slot) is wiped by its owner too:
         // writing EMPTY twice is harmless now that nothing of this row probes any more.
@@ -237,8 +255,8 @@ void k_wave_count(const int2 *__restrict__ ab, const int *__restrict__ Bcol,
 }
 
 template <int CHUNKS>
-static void launch_count_cfg(const int2 *ab, const int *Bcol, int cols, const RowRec *rec, int nrows, int row_begin,
-                             int *cnt, hipStream_t s)
+static void launch_count_cfg(const int *Acol, const int *Brow, const int *Bcol, int cols, int2 *ab,
+                             const RowRec *rec, int nrows, int row_begin, int *cnt, hipStream_t s)
 {
     using Cfg = CountCfg<CHUNKS>;
     constexpr int kSpreadWaves = 256 * 8;
@@ -249,18 +267,18 @@ static void launch_count_cfg(const int2 *ab, const int *Bcol, int cols, const Ro
     const int grid = (int)((nrows + rows_per_wg - 1) / rows_per_wg);
     if (cols <= (1 << 24))
         hipLaunchKernelGGL((k_wave_count<CHUNKS, false>), dim3(grid), dim3(64 * Cfg::WAVES), 0, s,
-                           ab, Bcol, rec, nrows, rpw, row_begin, cnt);
+                           Acol, Brow, Bcol, ab, rec, nrows, rpw, row_begin, cnt);
     else
         hipLaunchKernelGGL((k_wave_count<CHUNKS, true>), dim3(grid), dim3(64 * Cfg::WAVES), 0, s,
-                           ab, Bcol, rec, nrows, rpw, row_begin, cnt);
+                           Acol, Brow, Bcol, ab, rec, nrows, rpw, row_begin, cnt);
 }
 
-void launch_wave_count(int bin, const int2 *ab, const int *Bcol, int cols, const RowRec *rec, int nrows,
-                       int row_begin, int *cnt, hipStream_t s)
+void launch_wave_count(int bin, const int *Acol, const int *Brow, const int *Bcol, int cols, int2 *ab,
+                       const RowRec *rec, int nrows, int row_begin, int *cnt, hipStream_t s)
 {
     if (nrows <= 0) return;
     switch (bin) {
-#define BSP_CASE(b) case b: launch_count_cfg<kWaveChunks[b]>(ab, Bcol, cols, rec, nrows, row_begin, cnt, s); break;
+#define BSP_CASE(b) case b: launch_count_cfg<kWaveChunks[b]>(Acol, Brow, Bcol, cols, ab, rec, nrows, row_begin, cnt, s); break;
     BSP_CASE(1) BSP_CASE(2) BSP_CASE(3) BSP_CASE(4) BSP_CASE(5) BSP_CASE(6) BSP_CASE(7) BSP_CASE(8)
     BSP_CASE(9) BSP_CASE(10) BSP_CASE(11) BSP_CASE(12) BSP_CASE(13) BSP_CASE(14) BSP_CASE(15) BSP_CASE(16)
 #undef BSP_CASE

@@ -87,6 +87,21 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
                                 const bspgemm_matrix *A, const bspgemm_matrix *B,
                                 int row_begin, int row_end, bspgemm_result **C);
 
+/* How bspgemm_multiply gets from row sizes to C.col_idx.  Both give the same CSR, bit for bit.
+ *   UPPER_BOUND  rows are placed by their product count F_i (an upper bound of |C_i|) in a workspace
+ *                of F entries and squeezed into C.col_idx once the counts are scanned -- the GPU
+ *                form of the reference's append-then-concatenate (final/SpGEMM_mpi_omp.c:38-42,
+ *                110-131); holds 2F entries.
+ *   EXACT        a symbolic pass sizes every row exactly first (hash-set count kernels), C.row_ptr
+ *                is their scan, and the numeric pass emits every row at its final place: nnz(C)
+ *                entries, no F-sized workspace.
+ *   AUTO         (default, or env BSPGEMM_FLOW=auto|upper-bound|exact) UPPER_BOUND, and EXACT when
+ *                its buffers cannot be allocated.                                               */
+#define BSPGEMM_FLOW_AUTO        0
+#define BSPGEMM_FLOW_UPPER_BOUND 1
+#define BSPGEMM_FLOW_EXACT       2
+bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow);
+
 /* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):
  * a column k is admitted to row i only if (i,k) is in F's pattern.                           */
 bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx,
