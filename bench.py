@@ -315,7 +315,7 @@ def main():
         a_row = np.diff(rp.astype(np.int64))[r0:r1]
         c_row = np.diff(crp)
         caps = st["bin_cap"]
-        DENSE_BIN = len(caps) - 1
+        DENSE_BIN = 1 + sum(1 for c in caps[1:] if c <= 2048)    # first class that is not one-wave-per-row
         bins = bin_of(F_row, caps)
         levels = next((L for L in range(1, 5) if n <= (256 << (5 * L))), 5)      # csrc/kernels.hpp levels_for_cols
         if levels == 4 and n <= (512 << 15):

@@ -100,6 +100,7 @@ struct bspgemm_context {
         hipEvent_t ev[5] = {};                      // start / classes known / row sizes known / rows emitted / done
         hipEvent_t ev_cls[2][kNumBins][2] = {};     // per (phase, class): launch brackets
         int R = 0;
+        int mid_cap = 0;
         HostScalars h = {};
         long long products = 0, nnz_c = 0;
         int cls_n[2][kNumBins] = {};
@@ -470,14 +471,15 @@ static int class_streams_from_env()
 // class launch order of a phase: the heavy rows first (few long-running workgroups: started early
 // they finish under the other classes instead of being the phase's tail), then the one-wave
 // classes by capacity
-static inline int class_at(int pos) { return pos == 1 ? kDenseBin : pos - 1; }
+static inline int class_at(int pos) { return pos == 1 ? kDenseBin : (pos == 2 ? kMidBin : pos - 2); }
 
 // closes the multiply's stat slot (its events have all completed: the caller has synchronised)
 static void close_slot(bspgemm_context *ctx, int R, const HostScalars *h, long long products, long long nnz_c,
-                       const int (*cls_n)[kNumBins])
+                       const int (*cls_n)[kNumBins], int mid_cap)
 {
     bspgemm_context::StatSlot &sl = ctx->slots[ctx->slot_head];
     sl.R = R;
+    sl.mid_cap = mid_cap;
     sl.h = *h;
     sl.products = products;
     sl.nnz_c = nnz_c;
@@ -499,7 +501,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     st.bins = kNumBins;
     for (int b = 0; b < kNumBins; b++) {
         st.rows_per_bin[b] = sl.h.bin_count[b];
-        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : 64 * kWaveChunks[b]);
+        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : (b == kMidBin ? sl.mid_cap : 64 * kWaveChunks[b]));
     }
     hipEventElapsedTime(&st.ms_total, sl.ev[0], sl.ev[4]);
     hipEventElapsedTime(&st.ms_prepass, sl.ev[0], sl.ev[1]);
@@ -551,7 +553,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     if (bspgemm_status st = ensure_deg8(B)) return bail(st);       // (wrapped device arrays: first use)
     launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, row_begin, row_end, ctx->F, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, s);
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), s);
     HostScalars *h = ctx->h;
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->heavy_total, ctx->hpartials + scan_tiles, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -599,7 +601,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
                                   ctx->cnt, sx);
             } else {
                 launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
-                HIPCHK_B(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
@@ -640,7 +642,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
             // the heavy rows' move runs beside the class launches on the third stream
-            hipStream_t sx = b == kDenseBin ? sC : lanes[pos % nlanes];
+            hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
             HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
@@ -658,7 +660,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     HIPCHK_B(hipStreamSynchronize(s));
     (void)synced;
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, totalF, C->nnz, cls_n);
+    close_slot(ctx, R, h, totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols));
     *out = C;
     return BSPGEMM_OK;
 }
@@ -701,7 +703,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
         size_by = ctx->Fmask;
     }
     launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, s);
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), s);
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -741,7 +743,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
                                  ctx->tmp, ctx->cnt, sx);
             else if (!Fm)
-                HIPCHK_B(launch_dense_rows(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
             else if (b <= kWaveBins && wave_masked_supported(B->cols))
                 launch_wave_masked(b, ctx->ab, B->d_col_idx, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
@@ -776,7 +778,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_B(hipEventRecord(slot.ev[4], s));
     HIPCHK_B(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, (Fm && R > 0) ? h->products : total, C->nnz, cls_n);
+    close_slot(ctx, R, h, (Fm && R > 0) ? h->products : total, C->nnz, cls_n, mid_cap_for_cols(B->cols));
     *out = C;
     return BSPGEMM_OK;
 }
@@ -972,7 +974,7 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = ensure_deg8(B)) return st;
     launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, 0, R, ctx->F, ctx->stream);
     launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
-                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, ctx->stream);
+                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BSPGEMM_OK;

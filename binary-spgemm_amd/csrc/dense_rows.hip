@@ -18,17 +18,29 @@
 
 namespace bsp {
 
-constexpr int kDenseThreads = 1024;
+// Two shapes of the same kernel (class kDenseBin / kMidBin, kernels.hpp):
+//   1024 threads, window up to 2^20 columns (128 KiB): one workgroup per CU -- worth it for hub rows,
+//        whose tens of thousands of products amortise the latency of every phase;
+//    256 threads, window up to 2^18 columns (32 KiB): four workgroups (16 waves) per CU -- for the many
+//        rows with a few thousand products, which one workgroup per CU serialises phase by phase.
+constexpr int kDenseThreadsBig = 1024;
+constexpr int kDenseThreadsMid = 256;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
-constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
+#ifndef BSP_MID_WORDS
+#define BSP_MID_WORDS 4096
+#endif
+constexpr int kMidMaxWords = BSP_MID_WORDS;  // 4096 words = 2^18 columns = 32 KiB
 constexpr int kDenseWordBits = 12;           // 64-column words with at least this many outputs are emitted by a whole wave
-constexpr int kLongSrc = 128;                // B rows at least this long are loaded segment-wise by whole waves
+#ifndef BSP_LONG_SRC
+#define BSP_LONG_SRC 128
+#endif
+constexpr int kLongSrc = BSP_LONG_SRC;       // B rows at least this long are loaded segment-wise by whole waves
 
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
 // holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
 // set in P is set in K, and K is what gets read out.
-template <bool MASKED>
+template <bool MASKED, int kDenseThreads>
 __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
@@ -40,6 +52,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
                                                               const int *__restrict__ Frow,
                                                               const int *__restrict__ Fcol)
 {
+    constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 *bmP = reinterpret_cast<u64 *>(lds_raw);                       // products
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
                     const int pp = ok[u] ? p : 0;
                     int lo_s = 0, hi_s = kDenseBatch;          // s_pref[lo_s] <= pp < s_pref[hi_s]
 #pragma unroll
-                    for (int it = 0; it < 10; it++) {
+                    for (int it = 0; it < (kDenseThreads == 1024 ? 10 : 8); it++) {
                         const int mid = (lo_s + hi_s) >> 1;
                         if (s_pref[mid] <= pp) lo_s = mid; else hi_s = mid;
                     }
@@ -174,7 +187,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
         // read-out in column order: wave w owns the words [w*wpw, (w+1)*wpw), lane l of a step the
         // word l of the step's 64 -- a step's outputs are one contiguous piece of the row, written by
         // a handful of store instructions that each touch the same few cache lines
-        const int wpw = ((wwords + 15) / 16 + 63) & ~63;
+        constexpr int kWavesPerWg = kDenseThreads / 64;
+        const int wpw = ((wwords + kWavesPerWg - 1) / kWavesPerWg + 63) & ~63;
         const int wbeg = wave * wpw;
         const int wend = (wbeg + wpw < wwords) ? wbeg + wpw : wwords;
         int c = 0;
@@ -222,13 +236,14 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     if (tid == 0) cnt[i - row_begin] = total;
 }
 
-template <bool MASKED>
+template <bool MASKED, int THREADS>
 static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, const RowRec *rec,
                                     const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt,
                                     const int *Frow, const int *Fcol, hipStream_t s)
 {
     if (nrows <= 0) return hipSuccess;
-    const long long max_words = MASKED ? kDenseMaxWords / 2 : kDenseMaxWords;   // two bitmaps share the window
+    const long long cap_words = THREADS == kDenseThreadsBig ? kDenseMaxWords : kMidMaxWords;
+    const long long max_words = MASKED ? cap_words / 2 : cap_words;   // two bitmaps share the window
     long long words = ((long long)cols + 63) / 64;
     if (words > max_words) words = max_words;
     if (words < 1) words = 1;
@@ -238,28 +253,30 @@ static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, c
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_rows<MASKED>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_rows<MASKED, THREADS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap_words * 8);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((k_dense_rows<MASKED>), dim3(nrows), dim3(kDenseThreads), bytes, s, ab, Bcol,
+    hipLaunchKernelGGL((k_dense_rows<MASKED, THREADS>), dim3(nrows), dim3(THREADS), bytes, s, ab, Bcol,
                        cols, (int)words, rec, recpre, row_begin, tmp, cnt, Frow, Fcol);
     return hipGetLastError();
 }
 
-hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
+hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s)
 {
-    return launch_dense_impl<false>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
+    if (mid)
+        return launch_dense_impl<false, kDenseThreadsMid>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
+    return launch_dense_impl<false, kDenseThreadsBig>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
 }
 
 hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
                                     const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                                     int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s)
 {
-    return launch_dense_impl<true>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
+    return launch_dense_impl<true, kDenseThreadsBig>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
 }
 
 // ---------------------------------------------------------------------------------------

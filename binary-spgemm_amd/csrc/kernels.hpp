@@ -14,13 +14,32 @@ namespace bsp {
 //                straight-line over its CHUNKS 64-product chunks (exact s_waitcnt counts, no
 //                branches), so a row costs what its CLASS costs: the classes step by one chunk up
 //                to 512 products, by two up to 1024, then by four/eight
-//   kDenseBin  : dense-window rows (F_i > 2048)
+//   kMidBin    : dense-window rows, 2048 < F_i <= mid_cap_for_cols(cols): 256-thread workgroups, several per CU
+//   kDenseBin  : dense-window rows, above that: one 1024-thread workgroup per row
 constexpr int kWaveBins = 16;
-constexpr int kNumBins = kWaveBins + 2;
-constexpr int kDenseBin = kNumBins - 1;
+constexpr int kNumBins = kWaveBins + 3;
+constexpr int kMidBin = kWaveBins + 1;
+constexpr int kDenseBin = kWaveBins + 2;
 constexpr int kMaxBins = 20;            // size of the per-class arrays in bspgemm_stats
 constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
 constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
+// products up to which a heavy row takes the 256-thread shape: its 32 KiB window covers 2^18 columns,
+// so the row's products are gathered ceil(cols / 2^18) times -- the fewer passes, the larger the
+// rows it is good for (measured: Graph500-skew scale 18, one pass: 131072 beats 32768 by 9 %;
+// power-law n = 2^20, four passes: 8192 beats 32768 by 5 %)
+#ifndef BSP_MID_CAP1
+#define BSP_MID_CAP1 131072
+#endif
+#ifndef BSP_MID_CAPN
+#define BSP_MID_CAPN 32768
+#endif
+inline int mid_cap_for_cols(long long cols)
+{
+    const long long passes = (cols + (1ll << 18) - 1) >> 18;
+    if (passes <= 1) return BSP_MID_CAP1;
+    const long long c = BSP_MID_CAPN / passes;
+    return c < kMaxWaveCap ? kMaxWaveCap : (int)c;      // (== kMaxWaveCap: no row takes the 256-thread shape)
+}
 #ifndef BSP_RPW
 #define BSP_RPW 16
 #endif
@@ -83,7 +102,7 @@ void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const
 // holds that workspace's total size; one-wave rows are then placed by the symbolic counts.
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, hipStream_t s);
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, hipStream_t s);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
@@ -105,8 +124,8 @@ void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int 
 void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,
                         const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s);
 
-// numeric phase, one workgroup per heavy row (windowed dense LDS bitmap)
-hipError_t launch_dense_rows(const int2 *ab, const int *Bcol, int cols,
+// numeric phase, one workgroup per heavy row (windowed dense LDS bitmap); mid: the 256-thread shape
+hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 

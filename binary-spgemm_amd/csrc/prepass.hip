@@ -169,10 +169,10 @@ constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;   // 2048 values per workgroup
 
 // capacity class of a row with F products (see kernels.hpp)
-__device__ __forceinline__ int bin_of(long long F)
+__device__ __forceinline__ int bin_of(long long F, int mid_cap)
 {
     if (F <= 0) return 0;
-    if (F > kMaxWaveCap) return kDenseBin;
+    if (F > kMaxWaveCap) return F > mid_cap ? kDenseBin : kMidBin;
     const int f = (int)F;
     int b = 1;
 #pragma unroll
@@ -186,7 +186,8 @@ template <typename T, bool BIN>
 __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict__ in, int n,
                                                             long long *__restrict__ partials,
                                                             int *__restrict__ bin_tiles,
-                                                            int heavy_cols, long long *__restrict__ hpartials)
+                                                            int heavy_cols, long long *__restrict__ hpartials,
+                                                            int mid_cap)
 {
     __shared__ long long lds[4], ldh[4];
     __shared__ int lcount[kNumBins];
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
             const long long x = (long long)in[base + k];
             v += x;
             if (BIN) {
-                const int b = bin_of(x);
+                const int b = bin_of(x, mid_cap);
                 atomicAdd(&lcount[b], 1);
-                if (b == kDenseBin) hv += x < heavy_cols ? x : heavy_cols;
+                if (b > kWaveBins) hv += x < heavy_cols ? x : heavy_cols;
             }
         }
     v = wave_incl_scan64(v);
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              int *__restrict__ cnt,
                                                              const long long *carry_in,
                                                              int heavy_cols,
-                                                             const long long *__restrict__ hpartials)
+                                                             const long long *__restrict__ hpartials,
+                                                             int mid_cap)
 {
     __shared__ long long wsum[4], hsum[4];
     __shared__ int lcount[kNumBins];
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
         if (base + k < n) {
             out[base + k] = off;
             if (BIN) {
-                const int b = bin_of(v[k]);
+                const int b = bin_of(v[k], mid_cap);
                 if (b == 0) {
                     cnt[base + k] = 0;
                 } else {
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                     rec[pos] = q;
                     // where the row is first written: its upper-bound offset, or (heavy-row workspace
                     // in use) the heavy rows' own offsets; one-wave rows then never use recpre
-                    recpre[pos] = (heavy_cols > 0 && b == kDenseBin) ? hoff : off;
-                    if (heavy_cols > 0 && b == kDenseBin) hoff += v[k] < heavy_cols ? v[k] : heavy_cols;
+                    recpre[pos] = (heavy_cols > 0 && b > kWaveBins) ? hoff : off;
+                    if (heavy_cols > 0 && b > kWaveBins) hoff += v[k] < heavy_cols ? v[k] : heavy_cols;
                 }
             }
         }
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, hipStream_t s)
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, hipStream_t s)
 {
     if (n <= 0) {
         hipMemsetAsync(prefix, 0, sizeof(long long), s);
@@ -364,18 +366,18 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles,
-                       heavy_cols, hpartials);
+                       heavy_cols, hpartials, mid_cap);
     hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0, s, partials,
                        tiles, bin_tiles, bin_count, hpartials);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
-                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials);
+                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials, mid_cap);
 }
 
 void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s)
 {
     if (n <= 0) { hipMemsetAsync(partials, 0, sizeof(long long), s); return; }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr, 0);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
 }
 
@@ -389,10 +391,10 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -152,8 +152,9 @@ typedef struct bspgemm_stats {
     int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
     int64_t bytes_read_alg;  /* its HBM-read part: bytes_alg - 4nnzC - 8(rows+1)             */
     int64_t rows_per_bin[BSPGEMM_MAX_BINS]; /* rows per capacity class: [0] empty rows,
-                                [1..bins-2] one-wavefront rows with at most bin_cap[b] products,
-                                [bins-1] heavy rows (one workgroup each); rest unused        */
+                                [1..bins-3] one-wavefront rows with at most bin_cap[b] products,
+                                [bins-2], [bins-1] heavy rows (one 256- / 1024-thread workgroup
+                                each); rest unused                                           */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* = ms_prepass + ms_count: everything that sizes C.row_ptr     */
     float   ms_prepass;      /*   row work (products per row) + scan + capacity classes      */

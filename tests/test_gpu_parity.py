@@ -117,7 +117,8 @@ def test_against_oracle(ctx, name):
 
 
 def test_every_capacity_class_is_exercised(ctx):
-    """rows with F_i just below/above each class boundary 64,128,...,2048 and beyond"""
+    """rows with F_i just below/above each class boundary 64,128,...,2048, 131072 (the 256-thread heavy-row shape's cap
+    when one window covers the columns) and beyond"""
     n = 6000
     rng = np.random.default_rng(301)
     # B: row j has (j % 97) + 1 entries; A rows pick B rows so that F_i sweeps 1..4000
@@ -126,7 +127,7 @@ def test_every_capacity_class_is_exercised(ctx):
     b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, n)
     blen = np.diff(b_rp)
     caps = [64 * c for c in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32)]   # csrc/kernels.hpp kWaveChunks
-    targets = ([1, 2] + [t for cap in caps for t in (cap - 1, cap, cap + 1)] + [3000, 4000]) * 4
+    targets = ([1, 2] + [t for cap in caps for t in (cap - 1, cap, cap + 1)] + [3000, 4000, 100000, 280000]) * 4
     a_rows, a_cols = [], []
     for i, t in enumerate(targets):
         acc = 0
@@ -140,7 +141,7 @@ def test_every_capacity_class_is_exercised(ctx):
     erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, n)
     crp, cci, st = hip_product(ctx, a_rp, a_ci, n, b_rp, b_ci, n)
     assert_same(crp, cci, erp, eci)
-    assert st["bin_cap"][1:-1] == caps and st["bins"] == len(caps) + 2, st["bin_cap"]
+    assert st["bin_cap"][1:-2] == caps and st["bins"] == len(caps) + 3, st["bin_cap"]
     assert all(c > 0 for c in st["rows_per_bin"]), st["rows_per_bin"]
 
 
