@@ -709,7 +709,6 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipEventRecord(slot.ev[1], s));
-    HIPCHK_B(hipEventRecord(slot.ev[2], s));               // no separate count phase here
     HIPCHK_B(hipStreamSynchronize(s));
     const long long total = R > 0 ? h->totalF : 0;         // products (masked: sum of mask-row lengths): bounds nnz(C)
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
@@ -721,6 +720,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
         C->col_cap = total;
     }
     const int levels = wave_levels_for_cols(B->cols);
+    HIPCHK_B(hipEventRecord(slot.ev[2], s));               // no count phase here: ev[1]..ev[2] is the host's turn-around
 
     size_t bin_start[kNumBins + 1] = {0, 0};
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];

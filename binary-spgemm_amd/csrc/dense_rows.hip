@@ -288,7 +288,7 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // copies 16 B per lane whenever four outputs lie in one row -- stores are always 16-B aligned
 // and fully coalesced, loads are the same stream displaced by the row's shift.  Work per
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
-constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup
+constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup (a small product gets smaller chunks: see launch_compact)
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
 #ifndef BSP_COMPACT_INFLIGHT
 #define BSP_COMPACT_INFLIGHT 4
@@ -302,7 +302,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
                                                  const long long *__restrict__ row_ptr,
-                                                 int row_lo, int row_hi, int *__restrict__ col_idx)
+                                                 int row_lo, int row_hi, int chunk, int *__restrict__ col_idx)
 {
     __shared__ long long rp[kCompactBatch + 1];
     __shared__ long long sh[kCompactBatch];      // source offset - destination offset of the row
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
     const int tid = threadIdx.x;
     const long long out_lo = row_ptr[row_lo], out_hi = row_ptr[row_hi];
     // chunk starts are multiples of 4 outputs so that the 16-B stores stay aligned
-    long long o0 = (out_lo & ~3ll) + (long long)blockIdx.x * kCompactChunk;
-    long long o1 = o0 + kCompactChunk;
+    long long o0 = (out_lo & ~3ll) + (long long)blockIdx.x * chunk;
+    long long o1 = o0 + chunk;
     if (o0 < out_lo) o0 = out_lo;
     if (o1 > out_hi) o1 = out_hi;
     if (o0 >= o1) return;                        // uniform: the grid is sized by an upper bound
@@ -405,8 +405,13 @@ void launch_compact(const int *tmp, const long long *Fprefix, const long long *r
                     int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s)
 {
     if (row_hi <= row_lo || max_out <= 0) return;
-    const int grid = (int)((max_out + 3 + kCompactChunk - 1) / kCompactChunk) + 1;
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, row_lo, row_hi, col_idx);
+    // chunk: a multiple of 4 outputs (aligned 16-B stores); a small product is cut finer so that it
+    // still spreads over the chip (one 32768-output chunk would be ONE workgroup walking every row)
+    long long chunk = ((max_out / 2048) + 3) & ~3ll;
+    if (chunk < 256) chunk = 256;
+    if (chunk > kCompactChunk) chunk = kCompactChunk;
+    const int grid = (int)((max_out + 3 + chunk - 1) / chunk) + 1;
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, row_lo, row_hi, (int)chunk, col_idx);
 }
 
 }  // namespace bsp
