@@ -553,7 +553,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     if (bspgemm_status st = ensure_deg8(B)) return bail(st);       // (wrapped device arrays: first use)
     launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, row_begin, row_end, ctx->F, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), s);
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
     HostScalars *h = ctx->h;
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->heavy_total, ctx->hpartials + scan_tiles, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -694,23 +694,26 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
     HostScalars *h = ctx->h;
     h->products = 0;
-    const long long *size_by = ctx->F;          // what rows are binned and placed by: products ...
-    if (Fm) {                                   // ... or, masked, the mask row's length (|C_i| <= |F_i|)
-        launch_sum_i64(ctx->F, R, ctx->partials, s);
-        HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
-                                hipMemcpyDeviceToHost, s));
+    // rows are classified by their products and placed by min(products, B.cols) -- or, masked, both by
+    // the mask row's length (|C_i| <= |F_i|); the true product count is summed separately
+    const long long *size_by = ctx->F;
+    launch_sum_i64(ctx->F, R, ctx->partials, s);
+    HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
+                            hipMemcpyDeviceToHost, s));
+    if (Fm) {
         launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
         size_by = ctx->Fmask;
     }
     launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), s);
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols),
+                        B->cols > 0 ? B->cols : 1, s);
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipEventRecord(slot.ev[1], s));
     HIPCHK_B(hipStreamSynchronize(s));
-    const long long total = R > 0 ? h->totalF : 0;         // products (masked: sum of mask-row lengths): bounds nnz(C)
+    const long long total = R > 0 ? h->totalF : 0;         // sum of min(products, cols) (masked: of mask-row lengths): bounds nnz(C)
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
     if (bspgemm_status st = ensure_tmp(ctx, (size_t)total + 1)) return bail(st);
     // C.col_idx: a cached buffer of the upper-bound size is taken now (nothing to wait for); else it
@@ -778,7 +781,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_B(hipEventRecord(slot.ev[4], s));
     HIPCHK_B(hipStreamSynchronize(s));
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, (Fm && R > 0) ? h->products : total, C->nnz, cls_n, mid_cap_for_cols(B->cols));
+    close_slot(ctx, R, h, R > 0 ? h->products : 0, C->nnz, cls_n, mid_cap_for_cols(B->cols));
     *out = C;
     return BSPGEMM_OK;
 }
@@ -974,7 +977,7 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = ensure_deg8(B)) return st;
     launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, 0, R, ctx->F, ctx->stream);
     launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
-                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), ctx->stream);
+                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), 0, ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BSPGEMM_OK;

@@ -97,12 +97,16 @@ void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const
 // exclusive scan of F (int64) into prefix[0..n] and, fused, classification of every row into
 // the capacity classes: rec[] holds the non-empty rows grouped by class (class b starts at
 // sum(bin_count[1..b-1])), recpre[] their output offsets; bin_count[8] on the device.
+// bound_cols > 0: rows are CLASSIFIED by F_i but PLACED by min(F_i, bound_cols) (prefix[] and recpre[]
+// are offsets of that bound: a row cannot have more outputs than B has columns -- what keeps the
+// upper-bound workspace of a skewed product near nnz(C) instead of near F).
 // heavy_cols > 0: the heavy rows (class kDenseBin) get their own workspace offsets in recpre --
 // exclusive prefix of min(F_i, heavy_cols) over the heavy rows -- and hpartials[ceil(n/2048)]
 // holds that workspace's total size; one-wave rows are then placed by the symbolic counts.
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, hipStream_t s);
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
+                         hipStream_t s);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,

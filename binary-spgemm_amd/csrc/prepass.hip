@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
                                                             long long *__restrict__ partials,
                                                             int *__restrict__ bin_tiles,
                                                             int heavy_cols, long long *__restrict__ hpartials,
-                                                            int mid_cap)
+                                                            int mid_cap, int bound_cols)
 {
     __shared__ long long lds[4], ldh[4];
     __shared__ int lcount[kNumBins];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
     for (int k = 0; k < kScanItems; k++)
         if (base + k < n) {
             const long long x = (long long)in[base + k];
-            v += x;
+            v += (BIN && bound_cols > 0 && x > bound_cols) ? (long long)bound_cols : x;   // what is PLACED: |C_i| <= min(F_i, cols)
             if (BIN) {
                 const int b = bin_of(x, mid_cap);
                 atomicAdd(&lcount[b], 1);
@@ -286,18 +286,20 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              const long long *carry_in,
                                                              int heavy_cols,
                                                              const long long *__restrict__ hpartials,
-                                                             int mid_cap)
+                                                             int mid_cap, int bound_cols)
 {
     __shared__ long long wsum[4], hsum[4];
     __shared__ int lcount[kNumBins];
     __shared__ int lbase[kNumBins];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    long long v[kScanItems];
+    long long v[kScanItems];             // what rows are classified by (products)
+    long long pl[kScanItems];            // what they are placed by: the same, or bounded by the column count
     long long tsum = 0, hmine = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         v[k] = (base + k < n) ? (long long)in[base + k] : 0;
-        tsum += v[k];
+        pl[k] = (BIN && bound_cols > 0 && v[k] > bound_cols) ? (long long)bound_cols : v[k];
+        tsum += pl[k];
         if (BIN && v[k] > kMaxWaveCap) hmine += v[k] < heavy_cols ? v[k] : heavy_cols;
     }
     if (BIN && threadIdx.x < kNumBins) {
@@ -349,14 +351,15 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                 }
             }
         }
-        off += v[k];
+        off += pl[k];
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = base0 + partials[gridDim.x];
 }
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, hipStream_t s)
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
+                         hipStream_t s)
 {
     if (n <= 0) {
         hipMemsetAsync(prefix, 0, sizeof(long long), s);
@@ -366,18 +369,18 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles,
-                       heavy_cols, hpartials, mid_cap);
+                       heavy_cols, hpartials, mid_cap, bound_cols);
     hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0, s, partials,
                        tiles, bin_tiles, bin_count, hpartials);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
-                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials, mid_cap);
+                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials, mid_cap, bound_cols);
 }
 
 void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s)
 {
     if (n <= 0) { hipMemsetAsync(partials, 0, sizeof(long long), s); return; }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr, 0);
+    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr, 0, 0);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
 }
 
@@ -391,10 +394,10 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0);
+    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------
