@@ -619,12 +619,14 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     // without waiting for nnz(C); otherwise the size is read back and exactly that is allocated
     // (F itself when it is within 2 % of nnz(C): the next product of this shape then finds it cached).
     bool synced = false;
-    if (result_cached(ctx, result_bytes_colidx(totalF))) {
+    static const bool check = getenv("BSPGEMM_CHECK") != nullptr;   // development: never emit on unverified sizes
+    if (!check && result_cached(ctx, result_bytes_colidx(totalF))) {
         HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(totalF)));
         C->col_cap = totalF;
     } else {
         HIPCHK_B(hipStreamSynchronize(s));
         synced = true;
+        if (h->nnzC < 0 || h->nnzC > totalF) return bail(FAIL(BSPGEMM_ERR_HIP, "symbolic pass counted more outputs than products"));
         const long long want = (totalF - h->nnzC <= h->nnzC / 50 + 4096) ? totalF : h->nnzC;
         HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(want)));
         C->col_cap = want;
