@@ -230,6 +230,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # BSPGEMM_BENCH_SHARED_GPU=1: a FUNCTIONAL rehearsal of the N-rank path on a one-GPU box -- every rank
+    # uses GPU 0 and the collective runs over gloo (RCCL refuses two ranks on one device).  Its numbers
+    # say nothing about scaling; the JSON line is labelled.
+    shared_gpu = os.environ.get("BSPGEMM_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BSPGEMM_BENCH_FORCE_DIST") == "1"   # 1-rank rehearsal of the N>1 path
@@ -237,7 +243,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     t0 = time.perf_counter()
     rp, ci, n, wname, scaling = make_matrix(args, world)
@@ -297,10 +306,11 @@ def main():
     bin_ms = np.mean([h["ms_bin"] for h in hist], axis=0)
     bin_count_ms = np.mean([h["ms_bin_count"] for h in hist], axis=0)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if shared_gpu else dev
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([last.nnz, st["products"], st["bytes_alg"], st["bytes_read_alg"]], dtype=torch.int64, device=dev)
+        tot = torch.tensor([last.nnz, st["products"], st["bytes_alg"], st["bytes_read_alg"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         nnz_total, products_total, bytes_total, read_total = (int(x) for x in tot.tolist())
     else:
@@ -385,7 +395,7 @@ def main():
         "metric": "output nnz/sec (GNZ/s)", "value": round(value, 4), "unit": "GNZ/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not shared_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
         "config": {"workload": wname, "n": int(n), "nnz_a": int(rp[-1]), "products": products_total,
                    "nnz_c": nnz_total, "parallelism": "row-shards x%d cut at equal work, B replicated" % world,
                    "shard_rows": [int(b) for b in bounds.tolist()]},

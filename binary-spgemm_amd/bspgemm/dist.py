@@ -81,10 +81,10 @@ def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True, ctx=None):
     if detach and local_row_ptr.is_cuda:
         torch.cuda.current_stream(dev).synchronize()
     recv = torch.empty(world * width, dtype=torch.int32, device=dev)
-    if local_row_ptr.is_cuda and hasattr(dist, "all_gather_into_tensor"):
-        dist.all_gather_into_tensor(recv, send, group=group)
+    if local_row_ptr.is_cuda and dist.get_backend(group) == "nccl" and hasattr(dist, "all_gather_into_tensor"):
+        dist.all_gather_into_tensor(recv, send, group=group)           # RCCL: one flat collective
     else:
-        _all_gather_list(recv, send, world, group)
+        _all_gather_list(recv, send, world, group)                     # gloo (CPU tensors, or a shared-GPU rehearsal)
     if ctx is not None and local_row_ptr.is_cuda:
         out = torch.empty(R + 1, dtype=torch.int64, device=dev)
         ctx.lengths_to_row_ptr(recv.data_ptr(), world, width, bounds, out.data_ptr(),
@@ -101,6 +101,12 @@ def stitch_row_ptr(local_row_ptr, bounds, group=None, detach=True, ctx=None):
 
 
 def _all_gather_list(recv, send, world, group):
+    if send.is_cuda:                      # gloo has no all_gather on GPU tensors: stage through the host
+        host = send.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        recv.copy_(torch.cat(parts).to(recv.device))
+        return
     parts = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(parts, send, group=group)
     recv.copy_(torch.cat(parts))
