@@ -145,6 +145,10 @@ struct bspgemm_matrix {
     // per A-nonzero to size its rows (csrc/prepass.hip: k_row_products).  Part of the operand's
     // device layout: built when the operand is created (lazily for wrapped device arrays).
     mutable unsigned char *d_deg8 = nullptr;
+    // blocked extents table {row_ptr of every 8th row, 8 clamped lengths}: what k_row_work gathers per
+    // A-nonzero instead of a B.row_ptr pair (csrc/prepass.hip: k_row_work_blk); built on first use as B
+    mutable int *d_blk8 = nullptr;
+    mutable int blk8_state = 0;          // 0 undecided, 1 in use, 2 not worth it for this operand
 };
 
 static bspgemm_status ensure_deg8(const bspgemm_matrix *m)
@@ -153,6 +157,30 @@ static bspgemm_status ensure_deg8(const bspgemm_matrix *m)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_deg8), (size_t)m->rows + 1));
     launch_deg8(m->d_row_ptr, m->rows, m->d_deg8, m->ctx->stream);
     HIPCHK(hipGetLastError());
+    return BSPGEMM_OK;
+}
+
+// Whether products with `m` as B go through the blocked table.  It pays when B.row_ptr is several
+// times an XCD's 4 MB L2 (R-MAT scale 22: 16.8 MB, k_row_work 1.20 -> 0.92 ms) and the operand is not
+// dominated by rows of 255+ nonzeros, whose lengths the table clamps (power-law n = 2^20: B.row_ptr
+// fits L2 anyway and 10 % of the lookups fall through: 2.0 -> 3.0 ms; Graph500 skew: 70 % fall through).
+// Decided once per operand: one 8-byte read-back when the table is built.
+static bspgemm_status ensure_blk8(const bspgemm_matrix *m)
+{
+    if (m->blk8_state) return BSPGEMM_OK;
+    m->blk8_state = 2;
+    static const int force = getenv("BSPGEMM_RW_BLK") ? atoi(getenv("BSPGEMM_RW_BLK")) : -1;   // 0 never, 1 always
+    if (force == 0 || (force < 0 && m->rows < (1 << 21))) return BSPGEMM_OK;
+    const size_t ints = (size_t)3 * (((size_t)m->rows + 7) / 8 + 1);
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_blk8), (ints + 4) * sizeof(int)));
+    unsigned long long *d_clamped = reinterpret_cast<unsigned long long *>(m->d_blk8 + ((ints + 1) & ~(size_t)1));
+    HIPCHK(hipMemsetAsync(d_clamped, 0, sizeof(unsigned long long), m->ctx->stream));
+    launch_blk8(m->d_row_ptr, m->rows, m->d_blk8, d_clamped, m->ctx->stream);
+    HIPCHK(hipGetLastError());
+    unsigned long long clamped = 0;
+    HIPCHK(hipMemcpyAsync(&clamped, d_clamped, sizeof(clamped), hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    if (force == 1 || clamped * 8ull <= (unsigned long long)m->nnz) m->blk8_state = 1;
     return BSPGEMM_OK;
 }
 
@@ -316,6 +344,7 @@ extern "C" void bspgemm_matrix_free(bspgemm_matrix *m)
         hipFree(m->d_col_idx);
     }
     hipFree(m->d_deg8);
+    hipFree(m->d_blk8);
     delete m;
 }
 extern "C" int bspgemm_matrix_rows(const bspgemm_matrix *m) { return m ? m->rows : 0; }
@@ -693,7 +722,9 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, row_begin, row_end, ctx->F, ctx->ab, s);
+    if (bspgemm_status st = ensure_blk8(B)) return bail(st);
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr, row_begin, row_end,
+                    ctx->F, ctx->ab, s);
     HostScalars *h = ctx->h;
     h->products = 0;
     // rows are classified by their products and placed by min(products, B.cols) -- or, masked, both by

@@ -5,11 +5,11 @@
 // xb[k] becomes bit k of the LDS bitmap, test-and-set becomes ds_or_b32, and the quickSort of
 // the row (:47) disappears because the bitmap is read out in column order.  Rows this heavy have
 // many duplicate products, so the result is dense enough that scanning the window pays.
-// Gather: the row's A-nonzeros are taken 1024 at a time; their B-row extents (left by the
-// prepass) are scanned into a product-offset table in LDS, and the batch's products are then
-// spread evenly over the 1024 threads -- thread t takes products t, t+1024, ... and finds each
-// one's source row by a 10-step binary search in LDS -- four independent loads in flight per
-// thread, whatever the B-row lengths are.
+// Gather: the row's A-nonzeros are taken one per thread at a time; their B-row extents (left by the
+// prepass) are scanned into product offsets, and the batch's products are spread evenly over the
+// threads in tiles -- thread t takes products t, t+T, ... of a tile and finds each one's source row
+// by rank in a per-tile "starts" bitmap (the wave kernels' gather plan at workgroup scope) -- eight
+// independent loads in flight per thread, whatever the B-row lengths are.
 // When cols > 2^20 the row's products are re-gathered once per window (B is L2/MALL resident
 // for a hub row: its B rows were just read by the previous window).
 // Also holds the compaction kernels that squeeze the upper-bound-placed rows into C.col_idx.
@@ -25,23 +25,34 @@ namespace bsp {
 //        rows with a few thousand products, which one workgroup per CU serialises phase by phase.
 constexpr int kDenseThreadsBig = 1024;
 constexpr int kDenseThreadsMid = 256;
-constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
+#ifndef BSP_BIG_WORDS
+#define BSP_BIG_WORDS 16384
+#endif
+#ifndef BSP_BIG_MINW
+#define BSP_BIG_MINW 4
+#endif
+constexpr int kDenseMaxWords = BSP_BIG_WORDS;  // 64-bit words per window = 2^20 columns = 128 KiB
 #ifndef BSP_MID_WORDS
 #define BSP_MID_WORDS 4096
 #endif
 constexpr int kMidMaxWords = BSP_MID_WORDS;  // 4096 words = 2^18 columns = 32 KiB
 constexpr int kDenseWordBits = 12;           // 64-column words with at least this many outputs are emitted by a whole wave
-#ifndef BSP_LONG_SRC
-#define BSP_LONG_SRC 128
+#ifndef BSP_DENSE_TILE_PER_THREAD
+#define BSP_DENSE_TILE_PER_THREAD 32         // products per thread and tile (multiple of 4: one wave scans the tile's words)
 #endif
-constexpr int kLongSrc = BSP_LONG_SRC;       // B rows at least this long are loaded segment-wise by whole waves
+#ifndef BSP_DENSE_INFLIGHT
+#define BSP_DENSE_INFLIGHT 8
+#endif
+#ifndef BSP_DENSE_ABLATE             // timing only (WRONG results): 1 no window atomics, 2 + no B.col_idx loads, 3 + no read-out
+#define BSP_DENSE_ABLATE 0
+#endif
 
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
 // holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
 // set in P is set in K, and K is what gets read out.
 template <bool MASKED, int kDenseThreads>
-__global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__restrict__ ab,
+__global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? BSP_BIG_MINW : 4)) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
                                                               const RowRec *__restrict__ rec,
@@ -58,12 +69,16 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
     u64 *bm = MASKED ? bmP + wwords : bmP;                             // what is read out (K or P)
     u32 *bmK32 = reinterpret_cast<u32 *>(bm);
-    __shared__ int wtot[kDenseThreads / 64], wtot_ls[kDenseThreads / 64], wtot_lc[kDenseThreads / 64];
-    __shared__ int s_pref[kDenseBatch + 1];     // (short) product offset of each source in the batch
-    __shared__ int s_bs[kDenseBatch];           // B.row_ptr of each source
-    __shared__ int s_lbs[kDenseBatch], s_llen[kDenseBatch];   // compacted long sources: start, length
-    __shared__ int s_lseg[kDenseBatch + 1];     // ... and exclusive prefix of their 64-product segments
-
+    constexpr int kWaves = kDenseThreads / 64;
+    constexpr int kTile = kDenseThreads * BSP_DENSE_TILE_PER_THREAD;   // products per tile
+    constexpr int kTileWords = kTile / 32;
+    constexpr int kInFlight = BSP_DENSE_INFLIGHT;                      // B.col_idx loads a thread keeps in flight
+    static_assert(kTileWords % 64 == 0 && kTileWords <= kDenseThreads, "one wave scans the tile's words, blocked");
+    __shared__ int wtot[kWaves], wcnt[kWaves];
+    __shared__ long long wsum[kWaves];
+    __shared__ int sd[kDenseBatch];             // non-empty sources of the batch: B address - product index in the tile
+    __shared__ u32 tb[kTileWords];              // starts of the sources inside the current tile
+    __shared__ int tpre[kTileWords];            // (sources begun before word w) - 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < (MASKED ? 2 * wwords : wwords); t += kDenseThreads) bmP[t] = 0ull;
     __syncthreads();
@@ -78,97 +93,80 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
 
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
+        const int lo32 = (int)lo;
         for (int ja = a0; ja < a1; ja += kDenseBatch) {
-            // one source (A-nonzero) per thread.  LONG sources (>= kLongSrc products: in a heavy
-            // row of a skewed graph they carry nearly all the products) are cut into 64-product
-            // segments that whole waves load with no per-product search; the SHORT ones are
-            // flattened product by product.  Three block scans: short products, long segments,
-            // long sources (the latter compacts the long sources into their own list).
+            // One source (A-nonzero) per thread.  A block scan of the B-row lengths gives every source
+            // its offset in the batch's product order; the non-empty sources are squeezed into a list
+            // of (B address - product offset).  The products are then taken in TILES of kTile: a
+            // "starts" bitmap over the tile marks where each source begins, one wave turns its words
+            // into running source counts, and product p finds its source by rank -- word, count,
+            // popcount: two independent LDS reads and a dependent one, the same for B rows of 3 and of
+            // 30000 entries (round 1 walked long sources by segments and searched the short ones'
+            // offsets with ten dependent LDS reads per product) -- so that every thread can keep
+            // kInFlight B.col_idx loads in the air.
             int2 e = make_int2(0, 0);
             if (ja + tid < a1) e = ab[ja + tid];
-            const bool is_long = e.y >= kLongSrc;
-            const int v_sp = is_long ? 0 : e.y, v_ls = is_long ? (e.y + 63) >> 6 : 0, v_lc = is_long ? 1 : 0;
-            const int i_sp = wave_incl_scan(v_sp), i_ls = wave_incl_scan(v_ls), i_lc = wave_incl_scan(v_lc);
-            if (lane == 63) { wtot[wave] = i_sp; wtot_ls[wave] = i_ls; wtot_lc[wave] = i_lc; }
+            const int len = e.y;
+            const int inc = wave_incl_scan(len);
+            const u64 nonempty = __ballot(len > 0);
+            if (lane == 63) wsum[wave] = (long long)inc;
+            if (lane == 0) wcnt[wave] = __popcll(nonempty);
             __syncthreads();
-            int soff = i_sp - v_sp, pb = 0, o_ls = i_ls - v_ls, SL = 0, o_lc = i_lc - v_lc, NL = 0;
-            for (int k = 0; k < kDenseThreads / 64; k++) {
-                const int t = wtot[k], t2 = wtot_ls[k], t3 = wtot_lc[k];
-                if (k < wave) { soff += t; o_ls += t2; o_lc += t3; }
-                pb += t; SL += t2; NL += t3;
+            long long excl = (long long)(inc - len), PB = 0;
+            int cidx = __popcll(nonempty & mask_lt(lane));
+            for (int k = 0; k < kWaves; k++) {
+                const long long t = wsum[k];
+                const int c = wcnt[k];
+                if (k < wave) { excl += t; cidx += c; }
+                PB += t;
             }
-            s_pref[tid] = soff;
-            s_bs[tid] = e.x;
-            if (is_long) { s_lbs[o_lc] = e.x; s_llen[o_lc] = e.y; s_lseg[o_lc] = o_ls; }
-            if (tid == 0) { s_pref[kDenseBatch] = pb; s_lseg[NL] = SL; }
-            __syncthreads();
-            // long sources: wave w walks the segments [w*sspan, (w+1)*sspan), four loads in flight;
-            // the current source lives in registers and changes only when a segment index passes
-            // its last segment (wave-uniform compare, no search)
-            {
-                const int sspan = (SL + kDenseThreads / 64 - 1) / (kDenseThreads / 64);
-                int g = wave * sspan;
-                const int gend = (g + sspan < SL) ? g + sspan : SL;
-                if (g < gend) {
-                    int k = 0, hi_k = NL;                      // s_lseg[k] <= g < s_lseg[hi_k]
-                    while (hi_k - k > 1) {
-                        const int mid = (k + hi_k) >> 1;
-                        if (s_lseg[mid] <= g) k = mid; else hi_k = mid;
-                    }
-                    int seg0 = s_lseg[k], nxt = s_lseg[k + 1], lbs = s_lbs[k], llen = s_llen[k];
-                    for (; g < gend; g += 4) {
-                        int addr[4];
-                        bool ok[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int gg = g + u;
-                            const bool valid = gg < gend;
-                            while (valid && gg >= nxt) {       // uniform: next long source
-                                k++;
-                                seg0 = nxt;
-                                nxt = s_lseg[k + 1];
-                                lbs = s_lbs[k];
-                                llen = s_llen[k];
-                            }
-                            const int off = (gg - seg0) * 64 + lane;
-                            ok[u] = valid && off < llen;
-                            addr[u] = lbs + off;
-                        }
-                        int cv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; u++) cv[u] = ok[u] ? Bcol[addr[u]] : -1;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const long long c = (long long)cv[u] - lo;
-                            if (ok[u] && c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
-                        }
-                    }
+            for (long long T0 = 0; T0 < PB; T0 += kTile) {
+                __syncthreads();                                       // wcnt / tile arrays are free again
+                if (tid < kTileWords) tb[tid] = 0u;
+                const u64 earlier = __ballot(len > 0 && excl < T0);    // sources that began before the tile
+                if (lane == 0) wcnt[wave] = __popcll(earlier);
+                __syncthreads();
+                if (len > 0 && excl < T0 + kTile && excl + len > T0) {  // the source has products in this tile
+                    const int rel = (int)(excl - T0);                  // > -len: fits an int
+                    sd[cidx] = e.x - rel;                              // B address = sd + product index in the tile
+                    if (rel >= 0) atomicOr(&tb[rel >> 5], 1u << (rel & 31));
                 }
-            }
-            // short sources: their products evenly over the threads, 4 independent gathers in flight
-            for (int p0 = tid; p0 < pb; p0 += 4 * kDenseThreads) {
-                int addr[4];
-                bool ok[4];
+                __syncthreads();
+                if (wave == 0) {
+                    int before = -1;                                   // rank of a product's source - bits up to it
+                    for (int k = 0; k < kWaves; k++) before += wcnt[k];
+                    constexpr int WPL = kTileWords / 64;               // words per lane, blocked
+                    int c[WPL], run = 0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int p = p0 + u * kDenseThreads;
-                    ok[u] = p < pb;
-                    const int pp = ok[u] ? p : 0;
-                    int lo_s = 0, hi_s = kDenseBatch;          // s_pref[lo_s] <= pp < s_pref[hi_s]
+                    for (int k = 0; k < WPL; k++) { c[k] = run; run += __popc(tb[lane * WPL + k]); }
+                    const int wi = wave_incl_scan(run);
 #pragma unroll
-                    for (int it = 0; it < (kDenseThreads == 1024 ? 10 : 8); it++) {
-                        const int mid = (lo_s + hi_s) >> 1;
-                        if (s_pref[mid] <= pp) lo_s = mid; else hi_s = mid;
-                    }
-                    addr[u] = s_bs[lo_s] + (pp - s_pref[lo_s]);
+                    for (int k = 0; k < WPL; k++) tpre[lane * WPL + k] = before + wi - run + c[k];
                 }
-                int cv[4];
+                __syncthreads();
+                const int np = (PB - T0 < kTile) ? (int)(PB - T0) : kTile;
+                for (int k0 = 0; k0 < np; k0 += kInFlight * kDenseThreads) {
+                    int addr[kInFlight];
+                    bool ok[kInFlight];
 #pragma unroll
-                for (int u = 0; u < 4; u++) cv[u] = ok[u] ? Bcol[addr[u]] : -1;
+                    for (int u = 0; u < kInFlight; u++) {
+                        const int p = k0 + u * kDenseThreads + tid;
+                        ok[u] = p < np;
+                        const int pp = ok[u] ? p : 0;
+                        const u32 w = tb[pp >> 5];
+                        const int src = tpre[pp >> 5] + __popc(w & ((2u << (pp & 31)) - 1u));
+                        addr[u] = sd[src < 0 ? 0 : src] + pp;
+                    }
+                    int cv[kInFlight];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const long long c = (long long)cv[u] - lo;
-                    if (ok[u] && c >= 0 && c < W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                    for (int u = 0; u < kInFlight; u++)
+                        cv[u] = ok[u] ? (BSP_DENSE_ABLATE >= 2 ? addr[u] : Bcol[addr[u]]) : -1;
+#pragma unroll
+                    for (int u = 0; u < kInFlight; u++) {
+                        const u32 c = (u32)(cv[u] - lo32);                 // columns below the window wrap to huge values
+                        if (BSP_DENSE_ABLATE >= 1) { if (ok[u] && c == 0xfffffff0u) bm32[0] = 1u; }
+                        else if (ok[u] && c < (u32)W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                    }
                 }
             }
             __syncthreads();
@@ -192,6 +190,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
         const int wbeg = wave * wpw;
         const int wend = (wbeg + wpw < wwords) ? wbeg + wpw : wwords;
         int c = 0;
+        if (BSP_DENSE_ABLATE < 3)
         for (int w = wbeg + lane; w < wend; w += 64) c += __popcll(bm[w]);
         const int inc = wave_incl_scan(c);
         if (lane == 63) wtot[wave] = inc;
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_rows(const int2 *__rest
             btotal += t;
         }
         int run = total + off;                                 // wave-uniform output cursor
-        for (int w0 = wbeg; w0 < wend; w0 += 64) {
+        for (int w0 = wbeg; w0 < (BSP_DENSE_ABLATE >= 3 ? wbeg : wend); w0 += 64) {
             const int w = w0 + lane;
             u64 m = 0ull;
             if (w < wend) { m = bm[w]; bm[w] = 0ull; }
@@ -290,6 +289,9 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
 constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup (a small product gets smaller chunks: see launch_compact)
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
+#ifndef BSP_COMPACT_NOSLOW
+#define BSP_COMPACT_NOSLOW 0     // timing-only: 1 drops the groups that straddle a row boundary (WRONG results)
+#endif
 #ifndef BSP_COMPACT_INFLIGHT
 #define BSP_COMPACT_INFLIGHT 4
 #endif
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                 if (fast[u]) {
                     const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
                     __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
-                } else if (live[u]) {
+                } else if (live[u] && !BSP_COMPACT_NOSLOW) {
                     int r = lo_r[u];
                     for (int e = 0; e < 4; e++) {
                         const long long oe = o[u] + e;

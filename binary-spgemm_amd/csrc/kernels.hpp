@@ -83,8 +83,12 @@ struct RowRec {
 
 // F_i = sum_{j in A_i} |B_j| for rows [row_begin,row_end)  ->  F[i-row_begin];
 // ab[jj] = (B.row_ptr[A.col_idx[jj]], |B_j|) for every A-nonzero of those rows
-void launch_row_work(const int *Arow, const int *Acol, const int *Brow,
+// Bblk8 (may be null: gathers B.row_ptr pairs instead) = B's blocked extents table (launch_blk8)
+void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8,
                      int row_begin, int row_end, long long *F, int2 *ab, hipStream_t s);
+// blk[3b..3b+2] = {row_ptr[8b], lengths of rows 8b..8b+7 clamped to 255, one byte each}
+// *clamped_nnz (device, zeroed by the caller) += nonzeros in rows of 255 or more
+void launch_blk8(const int *row_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s);
 
 // deg8[i] = min(|row i|, 255): the per-operand byte table behind launch_row_products
 void launch_deg8(const int *row_ptr, int n, unsigned char *deg8, hipStream_t s);

@@ -69,14 +69,124 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
-void launch_row_work(const int *Arow, const int *Acol, const int *Brow,
+// ---------------------------------------------------------------------------------------
+// The same pass through B's BLOCKED extents table: per 8 rows of B one 12-byte entry
+// {row_ptr of the block's first row, the 8 row lengths clamped to 255}.  The table is 1.5 B per
+// row (6.3 MB at 4.2 M rows against 16.8 MB of B.row_ptr), so most of it stays in an XCD's 4 MB L2
+// on a skewed input and the 64-byte sectors that do come from the fabric are shared by 5 blocks
+// = 40 rows instead of 16.  start = base + sum of the lengths below the row in its block (two
+// v_sad_u8), length = the row's byte; a block with a clamped byte at or below the row is looked up
+// in B.row_ptr itself (rows of 255+ nonzeros: rare).
+struct __attribute__((packed, aligned(4))) Blk8 { int base; unsigned lo, hi; };   // 12 B, only dword aligned
+
+__global__ __launch_bounds__(256) void k_blk8(const int *__restrict__ row_ptr, int n, int *__restrict__ blk,
+                                              unsigned long long *__restrict__ clamped_nnz)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b * 8 >= n) return;
+    const int r0 = b * 8;
+    unsigned lo = 0u, hi = 0u;
+    long long clamped = 0;
+    int prev = row_ptr[r0];
+    const int base = prev;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int d = 0;
+        if (r0 + k < n) {
+            const int nx = row_ptr[r0 + k + 1];
+            d = nx - prev;
+            prev = nx;
+        }
+        const unsigned byte = (unsigned)(d < 255 ? d : 255);
+        if (d >= 255) clamped += d;
+        if (k < 4) lo |= byte << (8 * k); else hi |= byte << (8 * (k - 4));
+    }
+    // nonzeros that live in clamped rows: how skewed the operand is (the caller's switch, see api.hip)
+    if (clamped > 0) atomicAdd(clamped_nnz, (unsigned long long)clamped);
+    blk[3 * b] = base;
+    blk[3 * b + 1] = (int)lo;
+    blk[3 * b + 2] = (int)hi;
+}
+void launch_blk8(const int *row_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s)
+{
+    if (n <= 0) return;
+    const int nb = (n + 7) / 8;
+    hipLaunchKernelGGL(k_blk8, dim3((nb + 255) / 256), dim3(256), 0, s, row_ptr, n, blk, clamped_nnz);
+}
+
+__global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Arow,
+                                                      const int *__restrict__ Acol,
+                                                      const int *__restrict__ Brow,
+                                                      const int *__restrict__ Bblk,
+                                                      int row_begin, int nrows,
+                                                      long long *__restrict__ F,
+                                                      int2 *__restrict__ ab)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(gid >> 3);
+    const int sub = (int)(gid & 7);
+    long long sum = 0;
+    if (r < nrows) {
+        const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
+        constexpr int U = BSP_RW_UNROLL;
+        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {
+            int j[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            Blk8 w[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                w[u].base = 0; w[u].lo = w[u].hi = 0u;
+                if (j[u] >= 0) w[u] = *reinterpret_cast<const Blk8 *>(Bblk + 3 * (j[u] >> 3));
+            }
+            int start[U], len[U];
+            bool sat[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int k = j[u] & 7;
+                const u64 d = ((u64)w[u].hi << 32) | (u64)w[u].lo;
+                const u64 below = d & ((1ull << (8 * k)) - 1ull);
+                const u64 upto = (k == 7) ? d : (d & ((1ull << (8 * k + 8)) - 1ull));
+                const u64 v = ~upto;                                // a 255 byte at or below the row -> a zero byte here
+                sat[u] = j[u] >= 0 && ((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) != 0ull;
+                start[u] = w[u].base + (int)__builtin_amdgcn_sad_u8((unsigned)below, 0u, 0u)
+                           + (int)__builtin_amdgcn_sad_u8((unsigned)(below >> 32), 0u, 0u);
+                len[u] = (int)((d >> (8 * k)) & 255ull);
+            }
+            // clamped lengths (B rows of 255+ nonzeros -- the hubs of a skewed graph, so these reads hit
+            // L2): the exact pairs, again issued together
+            Int2U pr[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                pr[u].x = pr[u].y = 0;
+                if (sat[u]) pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (j[u] >= 0) {
+                    if (sat[u]) { start[u] = pr[u].x; len[u] = pr[u].y - pr[u].x; }
+                    ab[jj + 8 * u] = make_int2(start[u], len[u]);
+                    sum += (long long)len[u];
+                }
+        }
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    if (r < nrows && sub == 0) F[r] = sum;
+}
+
+void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8,
                      int row_begin, int row_end, long long *F, int2 *ab, hipStream_t s)
 {
     const int nrows = row_end - row_begin;
     if (nrows <= 0) return;
     const long long threads = (long long)nrows * 8;
     const int grid = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(k_row_work, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, row_begin, nrows, F, ab);
+    if (Bblk8)
+        hipLaunchKernelGGL(k_row_work_blk, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, Bblk8, row_begin, nrows, F, ab);
+    else
+        hipLaunchKernelGGL(k_row_work, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, row_begin, nrows, F, ab);
 }
 
 // ---------------------------------------------------------------------------------------
