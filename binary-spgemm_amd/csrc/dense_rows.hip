@@ -24,7 +24,13 @@ namespace bsp {
 //    256 threads, window up to 2^18 columns (32 KiB): four workgroups (16 waves) per CU -- for the many
 //        rows with a few thousand products, which one workgroup per CU serialises phase by phase.
 constexpr int kDenseThreadsBig = 1024;
-constexpr int kDenseThreadsMid = 256;
+#ifndef BSP_MID_THREADS
+#define BSP_MID_THREADS 256
+#endif
+#ifndef BSP_MID_MINW
+#define BSP_MID_MINW 4
+#endif
+constexpr int kDenseThreadsMid = BSP_MID_THREADS;
 #ifndef BSP_BIG_WORDS
 #define BSP_BIG_WORDS 16384
 #endif
@@ -52,7 +58,7 @@ constexpr int kDenseWordBits = 12;           // 64-column words with at least th
 // holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
 // set in P is set in K, and K is what gets read out.
 template <bool MASKED, int kDenseThreads>
-__global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? BSP_BIG_MINW : 4)) void k_dense_rows(const int2 *__restrict__ ab,
+__global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? BSP_BIG_MINW : BSP_MID_MINW)) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
                                                               const RowRec *__restrict__ rec,
