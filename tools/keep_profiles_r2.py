@@ -81,15 +81,22 @@ for flow, d in (("", "stats"), ("exact_flow_", "stats_exact")):
         family_timeline(os.path.join(DST, "%s_%srmat22_kernel_trace.csv" % (tag, flow)),
                         os.path.join(DST, "%s_%srmat22_family_timeline.txt" % (tag, flow)),
                         "bench.py --steps 10 --warmup 3" + (" (BSPGEMM_FLOW=exact)" if flow else ""))
-wl = json.load(open(os.path.join(SRC, "bench_rmat22.json")))["config"]["workload"]
+wl = None
+for cand in ("bench_rmat22.json", "pmc_ub/fetch.json", "pmc_ub/write.json"):
+    try:
+        wl = json.loads(open(os.path.join(SRC, cand)).read().strip().splitlines()[-1])["config"]["workload"]
+        break
+    except Exception:
+        continue
 for flow, d in (("", "pmc_ub"), ("exact_flow_", "pmc_exact")):
-    if os.path.isdir(os.path.join(SRC, d)):
+    if wl and os.path.isdir(os.path.join(SRC, d)):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(SRC, d), wl],
                              capture_output=True, text=True).stdout
         name = "%s_%spmc_traffic.json" % (tag, flow) if not flow else "%s_%spmc.json" % (tag, flow)
         open(os.path.join(DST, name), "w").write(out)
 for flow, d in (("", "sq_ub"), ("exact_flow_", "sq_exact")):
     copy(d + "/summary.txt", flow + "pmc_sq_summary.txt")
-for f in ("other_upper-bound.jsonl", "other_exact.jsonl", "flows.log", "small.log", "timeline.log", "masked.log"):
+for f in ("other_upper-bound.jsonl", "other_exact.jsonl", "flows.log", "small.log", "timeline.log", "masked.log",
+          "bins_powerlaw.log", "bins_g500.log"):
     copy(f, f.replace("other_", "other_workloads_"))
 print("\n".join(sorted(x for x in os.listdir(DST) if x.startswith(tag))))

@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from the rocprofv3 --pmc passes of tools/pmc_run.sh.
 usage: pmc_traffic.py <pmc dir> "<workload name as bench.py prints it>" > profiles/<round>_pmc_traffic.json
-FETCH_SIZE / WRITE_SIZE are reported in KiB; the value kept is the mean per dispatch * 1024."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB; the value kept is the mean per dispatch * 1024.
+Correction (MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies 128-byte requests at 64 bytes; calibrated for
+this library's access widths with tools/micro/fetch_calib.hip -> profiles/r02_fetch_calibration.txt):
+  coalesced streams of 4, 8 or 16 bytes per lane read 0.500 of their bytes  -> FETCH_SIZE x 2
+  random 64-byte rows (dword gathers) read 1.03 of their bytes              -> FETCH_SIZE x 1
+  WRITE_SIZE is exact for 4- and 16-byte-per-lane stores.
+A streaming kernel's fetch is doubled; a gather kernel mixes both kinds of request (B rows straddle
+64-byte sectors at random), so its fetch is bracketed: x1 (low) .. x2 (high)."""
 import collections
 import csv
 import glob
@@ -22,18 +29,26 @@ for name in sorted(acc):
     if not name.startswith("bsp::"):
         continue
     f, w = acc[name]["FETCH_SIZE"], acc[name]["WRITE_SIZE"]
-    kernels[name] = {"fetch_bytes": int(sum(f.values()) / max(len(f), 1) * 1024),
+    fb = int(sum(f.values()) / max(len(f), 1) * 1024)
+    gather = any(t in name for t in ("k_wave_rows", "k_wave_count", "k_wave_masked", "k_dense_rows", "k_row_work",
+                                     "k_row_products", "k_extents_of_rows"))
+    kernels[name] = {"fetch_bytes": fb, "fetch_bytes_corrected_low": fb if gather else 2 * fb,
+                     "fetch_bytes_corrected_high": 2 * fb, "access": "gather" if gather else "stream",
                      "write_bytes": int(sum(w.values()) / max(len(w), 1) * 1024),
                      "dispatches": max(len(f), len(w))}
 # one multiply = one dispatch of the row-size scan (k_scan_apply<int, false>); a kernel's dispatches per
 # step follow from that (the one-off bspgemm_row_work_prefix call of bench.py rounds away)
 n_mult = max([v["dispatches"] for k, v in kernels.items() if k.startswith("bsp::k_scan_apply<int, false>")] + [1])
-step_total = 0
+step_total = step_lo = step_hi = 0
 for k, v in kernels.items():
     v["dispatches_per_step"] = int(round(v["dispatches"] / n_mult))
     step_total += (v["fetch_bytes"] + v["write_bytes"]) * v["dispatches_per_step"]
-json.dump({"step_total_bytes": int(step_total), "multiplies_profiled": n_mult, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh) on `bench.py --steps 2 "
-                     "--warmup 1`; KiB*1024, mean per dispatch; FETCH_SIZE not corrected (gfx950 may under-count wide "
-                     "coalesced reads by 2x)",
+    step_lo += (v["fetch_bytes_corrected_low"] + v["write_bytes"]) * v["dispatches_per_step"]
+    step_hi += (v["fetch_bytes_corrected_high"] + v["write_bytes"]) * v["dispatches_per_step"]
+json.dump({"step_total_bytes": int(step_hi), "step_total_bytes_low": int(step_lo), "step_total_bytes_uncorrected": int(step_total),
+           "multiplies_profiled": n_mult, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc_run.sh) on `bench.py --steps 2 "
+                     "--warmup 1`; KiB*1024, mean per dispatch; FETCH_SIZE corrected for gfx950 (128-byte requests tallied at 64): "
+                     "x2 for streaming kernels, bracketed x1..x2 for gather kernels (step_total_bytes is the HIGH bound); "
+                     "calibration: profiles/r02_fetch_calibration.txt",
            "workload": workload, "kernels": kernels}, sys.stdout, indent=1)
 print()
