@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace bsp {
 
@@ -35,6 +36,8 @@ constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
 #endif
 inline int mid_cap_for_cols(long long cols)
 {
+    static const long long forced = getenv("BSPGEMM_MID_CAP") ? atoll(getenv("BSPGEMM_MID_CAP")) : 0;   // tuning knob
+    if (forced > 0) return forced < kMaxWaveCap ? kMaxWaveCap : (int)forced;
     const long long passes = (cols + (1ll << 18) - 1) >> 18;
     if (passes <= 1) return BSP_MID_CAP1;
     const long long c = BSP_MID_CAPN / passes;

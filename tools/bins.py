@@ -7,7 +7,7 @@ import torch, bspgemm
 which = sys.argv[1] if len(sys.argv) > 1 else "powerlaw"
 ctx = bspgemm.Context(0)
 if len(sys.argv) > 2:
-    ctx.set_flow({"auto": 0, "upper-bound": 1, "exact": 2}[sys.argv[2]])
+    ctx.set_flow(sys.argv[2])
 if which == "rmat22":
     rp, ci, n = bspgemm.gen_rmat(22, 16, (0.30, 0.25, 0.25), seed=1)
 elif which == "g500":

@@ -14,6 +14,7 @@ ctx = bspgemm.Context(0)
 t0 = time.perf_counter()
 for k in range(cases):
     kind = k % 5
+    ctx.set_flow(("upper-bound", "exact", "auto")[(k // 5) % 3])
     if kind == 0:
         sc = int(rng.integers(12, 17)); abc = [(0.30, 0.25, 0.25), (0.45, 0.22, 0.22), (0.57, 0.19, 0.19)][k // 5 % 3]
         rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(4, 24)), abc, seed=1000 + k)
@@ -54,8 +55,8 @@ for k in range(cases):
             frp, fci = O.spgemm_masked(rp, ci, b_rp, b_ci, ncols, rp, ci)
             mok = np.array_equal(mrp, frp) and np.array_equal(mci, fci)
             M.free()
-    print("case %2d kind %d rows %7d cols %9d products %.3g nnz %.3g  %s %s" %
-          (k, kind, n, ncols, st["products"], erp[-1], "OK" if ok else "MISMATCH", "" if mok else "MASKED MISMATCH"), flush=True)
+    print("case %2d %-11s kind %d rows %7d cols %9d products %.3g nnz %.3g  %s %s" %
+          (k, ("upper-bound", "exact", "auto")[(k // 5) % 3], kind, n, ncols, st["products"], erp[-1], "OK" if ok else "MISMATCH", "" if mok else "MASKED MISMATCH"), flush=True)
     C.free()
     if B is not A:
         B.free()
