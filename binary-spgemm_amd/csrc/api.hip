@@ -169,7 +169,7 @@ static bspgemm_status ensure_blk8(const bspgemm_matrix *m)
 {
     if (m->blk8_state) return BSPGEMM_OK;
     m->blk8_state = 2;
-    static const int force = getenv("BSPGEMM_RW_BLK") ? atoi(getenv("BSPGEMM_RW_BLK")) : -1;   // 0 never, 1 always
+    const int force = getenv("BSPGEMM_RW_BLK") ? atoi(getenv("BSPGEMM_RW_BLK")) : -1;   // 0 never, 1 always (read per operand)
     if (force == 0 || (force < 0 && m->rows < (1 << 21))) return BSPGEMM_OK;
     const size_t ints = (size_t)3 * (((size_t)m->rows + 7) / 8 + 1);
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_blk8), (ints + 4) * sizeof(int)));

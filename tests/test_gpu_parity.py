@@ -237,6 +237,52 @@ def test_tuning_knobs_do_not_change_results(ctx, env):
     assert_same(crp, cci, erp, eci)
 
 
+def test_blocked_extents_table_forced(ctx):
+    """k_row_work_blk (csrc/prepass.hip) is chosen per operand only for B of 2^21 rows or more; forced here on
+    small shapes that hit every branch of it: rows of 255+ nonzeros (clamped bytes -> exact lookup), a block
+    whose clamped byte lies below / at / above the looked-up row, the last partial block, rectangular A != B,
+    an interior row range, the masked product (the same prepass)."""
+    old = os.environ.get("BSPGEMM_RW_BLK")
+    os.environ["BSPGEMM_RW_BLK"] = "1"
+    try:
+        rng = np.random.default_rng(4242)
+        # B: 1003 rows (last block partial); hubs of 255, 256, 300 and 5000 nonzeros at block offsets 0, 3 and 7
+        lens = rng.integers(0, 40, size=1003)
+        for r, L in ((0, 255), (11, 256), (23, 300), (512, 5000), (1002, 700), (1000, 254)):
+            lens[r] = L
+        ncols = 9000
+        b_rows = np.repeat(np.arange(1003), lens)
+        b_cols = rng.integers(0, ncols, size=b_rows.size)
+        b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, 1003, dedup=False)       # exact lengths 254/255/256
+        a_rows = np.repeat(np.arange(700), rng.integers(0, 30, size=700))
+        a_cols = rng.integers(0, 1003, size=a_rows.size)
+        a_cols[:64] = np.array([0, 1, 7, 8, 11, 12, 15, 16, 23, 24, 512, 513, 519, 1000, 1001, 1002] * 4)
+        a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, 700)
+        erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+        crp, cci, st = hip_product(ctx, a_rp, a_ci, 1003, b_rp, b_ci, ncols)
+        assert_same(crp, cci, erp, eci)
+        # interior rows of a square power-law product + its masked form
+        rp, ci, n = bspgemm.gen_powerlaw(20_000, 24, seed=77)
+        rp, ci = np.asarray(rp), np.asarray(ci)
+        assert np.diff(rp).max() >= 255
+        erp, eci = O.spgemm(rp, ci, rp, ci, n)
+        A = ctx.upload(rp, ci, n)
+        C = ctx.multiply(A, A, 3000, 17000)
+        grp, gci = C.download()
+        assert np.array_equal(grp, erp[3000:17001] - erp[3000]) and np.array_equal(gci, eci[erp[3000]:erp[17000]])
+        M = ctx.multiply_masked(A, A, A)
+        mrp, mci = M.download()
+        frp, fci = O.spgemm_masked(rp, ci, rp, ci, n, rp, ci)
+        assert_same(mrp, mci, frp, fci)
+        for h in (C, M, A):
+            h.free()
+    finally:
+        if old is None:
+            os.environ.pop("BSPGEMM_RW_BLK", None)
+        else:
+            os.environ["BSPGEMM_RW_BLK"] = old
+
+
 def test_mostly_empty_rows(ctx):
     """a result whose 32768-output compaction chunks span far more than 4096 rows (every 40th row
     is non-empty): the per-output row search of k_compact; also the masked product of the same shape"""
