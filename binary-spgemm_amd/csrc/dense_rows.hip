@@ -49,6 +49,9 @@ constexpr int kDenseWordBits = 12;           // 64-column words with at least th
 #ifndef BSP_DENSE_INFLIGHT
 #define BSP_DENSE_INFLIGHT 8
 #endif
+#ifndef BSP_DENSE_NOEMIT             // timing only: 1 = counts kept, nothing emitted; 2 = loops run, stores dropped
+#define BSP_DENSE_NOEMIT 0
+#endif
 #ifndef BSP_DENSE_ABLATE             // timing only (WRONG results): 1 no window atomics, 2 + no B.col_idx loads, 3 + no read-out
 #define BSP_DENSE_ABLATE 0
 #endif
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                 PB += t;
             }
             for (long long T0 = 0; T0 < PB; T0 += kTile) {
-                __syncthreads();                                       // wcnt / tile arrays are free again
+                __syncthreads();                // wcnt / tile arrays are free again
                 if (tid < kTileWords) tb[tid] = 0u;
                 const u64 earlier = __ballot(len > 0 && excl < T0);    // sources that began before the tile
                 if (lane == 0) wcnt[wave] = __popcll(earlier);
@@ -188,11 +191,18 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             for (int t = tid; t < wwords; t += kDenseThreads) bmP[t] = 0ull;
             __syncthreads();
         }
-        // read-out in column order: wave w owns the words [w*wpw, (w+1)*wpw), lane l of a step the
-        // word l of the step's 64 -- a step's outputs are one contiguous piece of the row, written by
-        // a handful of store instructions that each touch the same few cache lines
+        // read-out in column order: wave w owns the words [w*wpw, (w+1)*wpw); a step takes 64*kWpl
+        // consecutive words, lane l the kWpl words behind 64-bit word kWpl*l of the step -- a lane's
+        // outputs are one contiguous piece of the row, the step's pieces follow each other.  kWpl = 4:
+        // ONE wave scan per 256 words (it was one per 64: in a window that is mostly empty -- a row with a
+        // few thousand products over 2^18 columns -- the scans were two thirds of the kernel's VALU work).
+#ifndef BSP_DENSE_WPL
+#define BSP_DENSE_WPL 4
+#endif
+        constexpr int kWpl = BSP_DENSE_WPL;
+        constexpr int kStepWords = 64 * kWpl;
         constexpr int kWavesPerWg = kDenseThreads / 64;
-        const int wpw = ((wwords + kWavesPerWg - 1) / kWavesPerWg + 63) & ~63;
+        const int wpw = ((wwords + kWavesPerWg - 1) / kWavesPerWg + kStepWords - 1) / kStepWords * kStepWords;
         const int wbeg = wave * wpw;
         const int wend = (wbeg + wpw < wwords) ? wbeg + wpw : wwords;
         int c = 0;
@@ -208,32 +218,48 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             btotal += t;
         }
         int run = total + off;                                 // wave-uniform output cursor
-        for (int w0 = wbeg; w0 < (BSP_DENSE_ABLATE >= 3 ? wbeg : wend); w0 += 64) {
-            const int w = w0 + lane;
-            u64 m = 0ull;
-            if (w < wend) { m = bm[w]; bm[w] = 0ull; }
-            const int cw = __popcll(m);
+        for (int w0 = wbeg; w0 < (BSP_DENSE_ABLATE >= 3 ? wbeg : wend); w0 += kStepWords) {
+            const int wl = w0 + kWpl * lane;                   // this lane's first word
+            u64 m[kWpl];
+            int cw = 0;
+#pragma unroll
+            for (int k = 0; k < kWpl; k++) {
+                m[k] = 0ull;
+                if (wl + k < wend) { m[k] = bm[wl + k]; bm[wl + k] = 0ull; }
+                cw += __popcll(m[k]);
+            }
             const int iw = wave_incl_scan(cw);
+            const int step_total = wave_bcast(iw, 63);
+            if (step_total == 0) continue;                     // uniform: an empty stretch of the window
             int pos = run + iw - cw;
-            const int base = (int)(lo + (long long)w * 64);
-            // dense words (hub columns: up to 64 bits set) are written by the whole wave, one word
-            // per store instruction, lane b holding bit b; the per-lane loop below then never runs
-            // longer than kDenseWordBits trips while the other lanes idle
-            u64 crowded = __ballot(cw >= kDenseWordBits);
-            while (crowded) {
-                const int src = (int)__builtin_ctzll(crowded);
-                crowded &= crowded - 1ull;
-                const u64 mw = wave_bcast64(m, src);
-                const int pw = wave_bcast(pos, src);
-                const int bw = wave_bcast(base, src);
-                if ((mw >> lane) & 1ull) out[pw + __popcll(mw & mask_lt(lane))] = bw | lane;
+            const int base = (int)(lo + (long long)wl * 64);
+#pragma unroll
+            for (int k = 0; k < kWpl; k++) {
+                const int ck = __popcll(m[k]);
+                // dense words (hub columns: up to 64 bits set) are written by the whole wave, one word
+                // per store instruction, lane b holding bit b; the per-lane loop below then never runs
+                // longer than kDenseWordBits trips while the other lanes idle
+                u64 crowded = __ballot(ck >= kDenseWordBits);
+                while (crowded) {
+                    const int src = (int)__builtin_ctzll(crowded);
+                    crowded &= crowded - 1ull;
+                    const u64 mw = wave_bcast64(m[k], src);
+                    const int pw = wave_bcast(pos, src);
+                    const int bw = wave_bcast(base, src) + 64 * k;
+                    if (BSP_DENSE_NOEMIT != 2 && ((mw >> lane) & 1ull)) out[pw + __popcll(mw & mask_lt(lane))] = bw | lane;
+                }
+                u64 mk = (ck >= kDenseWordBits || BSP_DENSE_NOEMIT == 1) ? 0ull : m[k];
+                int p = pos;
+                int sinkv = 0;
+                while (mk) {
+                    if (BSP_DENSE_NOEMIT == 2) sinkv ^= ((base + 64 * k) | (int)__builtin_ctzll(mk)) + p++;
+                    else out[p++] = (base + 64 * k) | (int)__builtin_ctzll(mk);
+                    mk &= mk - 1ull;
+                }
+                if (BSP_DENSE_NOEMIT == 2 && sinkv == 0x7fffffff) out[0] = sinkv;
+                pos += ck;
             }
-            if (cw >= kDenseWordBits) m = 0ull;
-            while (m) {
-                out[pos++] = base | (int)__builtin_ctzll(m);
-                m &= m - 1ull;
-            }
-            run += wave_bcast(iw, 63);
+            run += step_total;
         }
         total += btotal;
         __syncthreads();
