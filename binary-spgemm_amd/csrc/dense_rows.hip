@@ -21,14 +21,15 @@ namespace bsp {
 // Two shapes of the same kernel (class kDenseBin / kMidBin, kernels.hpp):
 //   1024 threads, window up to 2^20 columns (128 KiB): one workgroup per CU -- worth it for hub rows,
 //        whose tens of thousands of products amortise the latency of every phase;
-//    256 threads, window up to 2^18 columns (32 KiB): four workgroups (16 waves) per CU -- for the many
-//        rows with a few thousand products, which one workgroup per CU serialises phase by phase.
+//    512 threads, window up to 2^18 columns (32 KiB): four workgroups (32 waves) per CU -- for the many
+//        rows with thousands of products, which one workgroup per CU serialises phase by phase
+//        (256 threads: the same four rows in flight with half the waves to cover their latencies).
 constexpr int kDenseThreadsBig = 1024;
 #ifndef BSP_MID_THREADS
-#define BSP_MID_THREADS 256
+#define BSP_MID_THREADS 512
 #endif
 #ifndef BSP_MID_MINW
-#define BSP_MID_MINW 4
+#define BSP_MID_MINW 8               // four 8-wave workgroups per CU: 64 VGPRs
 #endif
 constexpr int kDenseThreadsMid = BSP_MID_THREADS;
 #ifndef BSP_BIG_WORDS

@@ -15,7 +15,7 @@ namespace bsp {
 //                straight-line over its CHUNKS 64-product chunks (exact s_waitcnt counts, no
 //                branches), so a row costs what its CLASS costs: the classes step by one chunk up
 //                to 512 products, by two up to 1024, then by four/eight
-//   kMidBin    : dense-window rows, 2048 < F_i <= mid_cap_for_cols(cols): 256-thread workgroups, several per CU
+//   kMidBin    : dense-window rows, 2048 < F_i <= mid_cap_for_cols(cols): 512-thread workgroups, four per CU
 //   kDenseBin  : dense-window rows, above that: one 1024-thread workgroup per row
 constexpr int kWaveBins = 16;
 constexpr int kNumBins = kWaveBins + 3;
@@ -24,15 +24,16 @@ constexpr int kDenseBin = kWaveBins + 2;
 constexpr int kMaxBins = 20;            // size of the per-class arrays in bspgemm_stats
 constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
 constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
-// products up to which a heavy row takes the 256-thread shape: its 32 KiB window covers 2^18 columns,
-// so the row's products are gathered ceil(cols / 2^18) times -- the fewer passes, the larger the
-// rows it is good for (measured: Graph500-skew scale 18, one pass: 131072 beats 32768 by 9 %;
-// power-law n = 2^20, four passes: 8192 beats 32768 by 5 %)
+// products up to which a heavy row takes the small (512-thread) shape: its 32 KiB window covers 2^18
+// columns, so the row's products are gathered ceil(cols / 2^18) times -- the fewer passes, the larger
+// the rows it is good for.  Swept with BSPGEMM_MID_CAP on the round-2 build (numeric phase, ms):
+// Graph500-skew scale 18 (one pass) 131072: 6.47, 524288: 5.87, 4194304: 6.18; power-law n = 2^20 (four
+// passes) 8192: 13.18, 32768: 12.88, 131072: 12.59, 262144: 12.96 -- i.e. 524288 / passes in both cases.
 #ifndef BSP_MID_CAP1
-#define BSP_MID_CAP1 131072
+#define BSP_MID_CAP1 524288
 #endif
 #ifndef BSP_MID_CAPN
-#define BSP_MID_CAPN 32768
+#define BSP_MID_CAPN 524288
 #endif
 inline int mid_cap_for_cols(long long cols)
 {
@@ -41,7 +42,7 @@ inline int mid_cap_for_cols(long long cols)
     const long long passes = (cols + (1ll << 18) - 1) >> 18;
     if (passes <= 1) return BSP_MID_CAP1;
     const long long c = BSP_MID_CAPN / passes;
-    return c < kMaxWaveCap ? kMaxWaveCap : (int)c;      // (== kMaxWaveCap: no row takes the 256-thread shape)
+    return c < kMaxWaveCap ? kMaxWaveCap : (int)c;      // (== kMaxWaveCap: no row takes the small shape)
 }
 #ifndef BSP_RPW
 #define BSP_RPW 16
@@ -135,7 +136,7 @@ void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int 
 void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,
                         const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s);
 
-// numeric phase, one workgroup per heavy row (windowed dense LDS bitmap); mid: the 256-thread shape
+// numeric phase, one workgroup per heavy row (windowed dense LDS bitmap); mid: the 512-thread shape
 hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
