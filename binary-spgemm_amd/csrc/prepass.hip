@@ -22,6 +22,41 @@ namespace bsp {
 
 struct __attribute__((packed, aligned(4))) Int2U { int x, y; };   // 8 B, only dword aligned
 
+#ifndef BSP_RW_UNROLL
+#define BSP_RW_UNROLL 4
+#endif
+#ifndef BSP_RW_LONG_ROW
+#define BSP_RW_LONG_ROW 256
+#endif
+// A wave holds 8 rows, 8 lanes each.  Rows of more than kLongRow nonzeros are first swept by ALL 64
+// lanes, one row at a time (a hub row of 36000 nonzeros was 1136 dependent trips of its 8 lanes: the
+// whole prepass of a power-law input waited for it); the others by their own 8 lanes.  `sweep(first, end,
+// stride)` handles nonzeros first, first+stride, ... and returns the lane's partial sum; the result is the
+// row's sum in the row's lane 0 (sub == 0).
+constexpr int kLongRow = BSP_RW_LONG_ROW;
+template <typename Sweep>
+__device__ __forceinline__ long long rows_of_a_wave(int a0, int a1, int sub, Sweep &&sweep)
+{
+    const int lane = threadIdx.x & 63;
+    long long long_sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int qa0 = __builtin_amdgcn_readlane(a0, q * 8), qa1 = __builtin_amdgcn_readlane(a1, q * 8);
+        if (qa1 - qa0 > kLongRow) {                                // wave-uniform
+            long long t = sweep((long long)qa0 + lane, (long long)qa1, 64);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) t += __shfl_xor(t, d, 64);
+            if (lane == q * 8) long_sum = t;
+        }
+    }
+    const bool is_long = a1 - a0 > kLongRow;
+    long long sum = is_long ? 0ll : sweep((long long)a0 + sub, (long long)a1, 8);
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    return is_long ? long_sum : sum;
+}
+
 // ---------------------------------------------------------------------------------------
 // 8 lanes per A row: lanes stride the row's col_idx (coalesced 32-B pieces), gather the
 // B.row_ptr pair of every nonzero, reduce over the 8 lanes.
@@ -35,19 +70,17 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int r = (int)(gid >> 3);
     const int sub = (int)(gid & 7);
-    long long sum = 0;
-    if (r < nrows) {
-        const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
-#ifndef BSP_RW_UNROLL
-#define BSP_RW_UNROLL 4
-#endif
-        // U nonzeros per lane and trip: their A.col_idx loads, then their B.row_ptr gathers, are
-        // issued together (independent misses in flight instead of one dependent chain per nonzero)
-        constexpr int U = BSP_RW_UNROLL;
-        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {      // 64-bit: jj + 8u may pass INT_MAX
+    int a0 = 0, a1 = 0;
+    if (r < nrows) { a0 = Arow[row_begin + r]; a1 = Arow[row_begin + r + 1]; }
+    // U nonzeros per lane and trip: their A.col_idx loads, then their B.row_ptr gathers, are
+    // issued together (independent misses in flight instead of one dependent chain per nonzero)
+    constexpr int U = BSP_RW_UNROLL;
+    auto sweep = [&](long long first, long long end, int stride) {
+        long long sum = 0;
+        for (long long jj = first; jj < end; jj += (long long)stride * U) {   // 64-bit: jj + stride*u may pass INT_MAX
             int j[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            for (int u = 0; u < U; u++) j[u] = (jj + stride * u < end) ? Acol[jj + stride * u] : -1;
             Int2U pr[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -58,14 +91,13 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
             for (int u = 0; u < U; u++)
                 if (j[u] >= 0) {
                     const int len = pr[u].y - pr[u].x;
-                    ab[jj + 8 * u] = make_int2(pr[u].x, len);
+                    ab[jj + stride * u] = make_int2(pr[u].x, len);
                     sum += (long long)len;
                 }
         }
-    }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
+        return sum;
+    };
+    const long long sum = rows_of_a_wave(a0, a1, sub, sweep);
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
@@ -125,14 +157,15 @@ __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Ar
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int r = (int)(gid >> 3);
     const int sub = (int)(gid & 7);
-    long long sum = 0;
-    if (r < nrows) {
-        const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
-        constexpr int U = BSP_RW_UNROLL;
-        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {
+    int a0 = 0, a1 = 0;
+    if (r < nrows) { a0 = Arow[row_begin + r]; a1 = Arow[row_begin + r + 1]; }
+    constexpr int U = BSP_RW_UNROLL;
+    auto sweep = [&](long long first, long long end, int stride) {
+        long long sum = 0;
+        for (long long jj = first; jj < end; jj += (long long)stride * U) {
             int j[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            for (int u = 0; u < U; u++) j[u] = (jj + stride * u < end) ? Acol[jj + stride * u] : -1;
             Blk8 w[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -165,14 +198,13 @@ __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Ar
             for (int u = 0; u < U; u++)
                 if (j[u] >= 0) {
                     if (sat[u]) { start[u] = pr[u].x; len[u] = pr[u].y - pr[u].x; }
-                    ab[jj + 8 * u] = make_int2(start[u], len[u]);
+                    ab[jj + stride * u] = make_int2(start[u], len[u]);
                     sum += (long long)len[u];
                 }
         }
-    }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
+        return sum;
+    };
+    const long long sum = rows_of_a_wave(a0, a1, sub, sweep);
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
@@ -219,14 +251,15 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ Ar
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int r = (int)(gid >> 3);
     const int sub = (int)(gid & 7);
-    long long sum = 0;
-    if (r < nrows) {
-        const int a0 = Arow[row_begin + r], a1 = Arow[row_begin + r + 1];
-        constexpr int U = 4;                                       // independent gathers in flight per lane
-        for (long long jj = a0 + sub; jj < a1; jj += 8 * U) {
+    int a0 = 0, a1 = 0;
+    if (r < nrows) { a0 = Arow[row_begin + r]; a1 = Arow[row_begin + r + 1]; }
+    constexpr int U = 4;                                           // independent gathers in flight per lane
+    auto sweep = [&](long long first, long long end, int stride) {
+        long long sum = 0;
+        for (long long jj = first; jj < end; jj += (long long)stride * U) {
             int j[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) j[u] = (jj + 8 * u < a1) ? Acol[jj + 8 * u] : -1;
+            for (int u = 0; u < U; u++) j[u] = (jj + stride * u < end) ? Acol[jj + stride * u] : -1;
             int d[U];
 #pragma unroll
             for (int u = 0; u < U; u++) d[u] = j[u] >= 0 ? (int)Bdeg8[j[u]] : 0;
@@ -236,10 +269,9 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ Ar
                 sum += (long long)d[u];
             }
         }
-    }
-    sum += __shfl_xor(sum, 1, 64);
-    sum += __shfl_xor(sum, 2, 64);
-    sum += __shfl_xor(sum, 4, 64);
+        return sum;
+    };
+    const long long sum = rows_of_a_wave(a0, a1, sub, sweep);
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
