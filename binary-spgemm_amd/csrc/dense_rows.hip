@@ -101,6 +101,15 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     const int nwin = (int)(((long long)cols + W - 1) / W);
     int total = 0;
 
+    // A row of one batch and one tile keeps its gather plan (sd, tb, tpre in LDS) for the later windows:
+    // they then start at the loads -- no extents, no block scan, no tile bitmap, none of their barriers
+    // (on a wide matrix most rows of the small shape are like that, and each of these phases is a
+    // latency the row's few waves cannot hide).
+#ifndef BSP_DENSE_KEEP_PLAN
+#define BSP_DENSE_KEEP_PLAN 1
+#endif
+    long long PB = 0;
+    bool plan_kept = false;                                            // uniform
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         const int lo32 = (int)lo;
@@ -115,22 +124,28 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             // offsets with ten dependent LDS reads per product) -- so that every thread can keep
             // kInFlight B.col_idx loads in the air.
             int2 e = make_int2(0, 0);
-            if (ja + tid < a1) e = ab[ja + tid];
-            const int len = e.y;
-            const int inc = wave_incl_scan(len);
-            const u64 nonempty = __ballot(len > 0);
-            if (lane == 63) wsum[wave] = (long long)inc;
-            if (lane == 0) wcnt[wave] = __popcll(nonempty);
-            __syncthreads();
-            long long excl = (long long)(inc - len), PB = 0;
-            int cidx = __popcll(nonempty & mask_lt(lane));
-            for (int k = 0; k < kWaves; k++) {
-                const long long t = wsum[k];
-                const int c = wcnt[k];
-                if (k < wave) { excl += t; cidx += c; }
-                PB += t;
+            int len = 0, cidx = 0;
+            long long excl = 0;
+            if (!plan_kept) {
+                if (ja + tid < a1) e = ab[ja + tid];
+                len = e.y;
+                const int inc = wave_incl_scan(len);
+                const u64 nonempty = __ballot(len > 0);
+                if (lane == 63) wsum[wave] = (long long)inc;
+                if (lane == 0) wcnt[wave] = __popcll(nonempty);
+                __syncthreads();
+                excl = (long long)(inc - len);
+                PB = 0;
+                cidx = __popcll(nonempty & mask_lt(lane));
+                for (int k = 0; k < kWaves; k++) {
+                    const long long t = wsum[k];
+                    const int c = wcnt[k];
+                    if (k < wave) { excl += t; cidx += c; }
+                    PB += t;
+                }
             }
             for (long long T0 = 0; T0 < PB; T0 += kTile) {
+                if (!plan_kept) {
                 __syncthreads();                // wcnt / tile arrays are free again
                 if (tid < kTileWords) tb[tid] = 0u;
                 const u64 earlier = __ballot(len > 0 && excl < T0);    // sources that began before the tile
@@ -154,6 +169,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                     for (int k = 0; k < WPL; k++) tpre[lane * WPL + k] = before + wi - run + c[k];
                 }
                 __syncthreads();
+                }
                 const int np = (PB - T0 < kTile) ? (int)(PB - T0) : kTile;
                 for (int k0 = 0; k0 < np; k0 += kInFlight * kDenseThreads) {
                     int addr[kInFlight];
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             }
             __syncthreads();
         }
+        if (BSP_DENSE_KEEP_PLAN && win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && PB <= kTile && PB > 0;
         if (MASKED) {
             // keep the product bits that F's row admits, then wipe P for the next window / row
             const int f0 = Frow[i], f1 = Frow[i + 1];
