@@ -321,8 +321,8 @@ class Context:
         _chk(lib().bspgemm_synchronize(self._h), "synchronize")
 
     def set_flow(self, flow):
-        """"auto" | "upper-bound" | "exact" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
-        _chk(lib().bspgemm_set_flow(self._h, {"auto": 0, "upper-bound": 1, "exact": 2}[flow]), "set_flow")
+        """"auto" | "upper-bound" | "exact" | "fused" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
+        _chk(lib().bspgemm_set_flow(self._h, {"auto": 0, "upper-bound": 1, "exact": 2, "fused": 3}[flow]), "set_flow")
 
     def upload(self, row_ptr, col_idx, cols, row0=0, rows=None):
         """Host CSR -> device.  row0/rows select an interior row range (absolute row_ptr values)."""

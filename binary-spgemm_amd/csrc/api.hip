@@ -84,6 +84,8 @@ struct HostScalars {
     int a_lo, a_hi;
     long long products;                 // true product count of a masked multiply (totalF is the mask total there)
     long long heavy_total;              // entries the heavy rows may need in the workspace
+    long long pack_totals[2];           // fused flow: number of tiles, sum of min(F_i, cols)
+    unsigned chain_err;                 // fused flow: a look-back wait ran out
 };
 
 struct bspgemm_context {
@@ -123,6 +125,15 @@ struct bspgemm_context {
     // upper-bound placed rows: the heavy rows of a plain product, every row of a masked one
     size_t tmp_cap = 0;
     int *tmp = nullptr;
+    // fused flow (csrc/tile_rows.inc): tile descriptors, look-back chain, packer scratch
+    size_t fused_cap = 0;               // rows these are sized for
+    TileDesc *tiles = nullptr;
+    unsigned long long *chain = nullptr;
+    unsigned char *marks8 = nullptr;
+    int *tile_count = nullptr;
+    long long *tile_bound = nullptr;
+    long long *pack_totals = nullptr;   // 2
+    unsigned *tickets = nullptr;        // 8 counters 32 words apart, then the error word
     HostScalars *h = nullptr;          // pinned
     // freed result buffers, reused by the next multiply (results are allocated per call like the
     // reference's per-call malloc of Ccol, final/SpGEMM_mpi_omp.c:115, without paying hipMalloc)
@@ -239,7 +250,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     for (auto &t : ctx->ev_tile) for (auto &e : t) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->cache_budget = prop.totalGlobalMem / 4;
     if (const char *e = getenv("BSPGEMM_FLOW"))
-        ctx->flow = !strcmp(e, "exact") ? BSPGEMM_FLOW_EXACT : (!strcmp(e, "upper-bound") || !strcmp(e, "ub")) ? BSPGEMM_FLOW_UPPER_BOUND
+        ctx->flow = !strcmp(e, "fused") ? BSPGEMM_FLOW_FUSED : !strcmp(e, "exact") ? BSPGEMM_FLOW_EXACT : (!strcmp(e, "upper-bound") || !strcmp(e, "ub")) ? BSPGEMM_FLOW_UPPER_BOUND
                                                                                                                : BSPGEMM_FLOW_AUTO;
     if (getenv("BSPGEMM_DEBUG_ALLOC"))
         fprintf(stderr, "[bspgemm] device %d: %s, %zu MiB, %d CUs; result cache budget %zu MiB\n", device,
@@ -256,6 +267,8 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
     hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
+    hipFree(ctx->tiles); hipFree(ctx->chain); hipFree(ctx->marks8); hipFree(ctx->tile_count); hipFree(ctx->tile_bound);
+    hipFree(ctx->pack_totals); hipFree(ctx->tickets);
     if (ctx->h) hipHostFree(ctx->h);
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) if (e) hipEventDestroy(e);
@@ -387,6 +400,28 @@ static bspgemm_status ensure_ab(bspgemm_context *ctx, size_t pairs)
     const size_t cap = pairs + pairs / 16 + 64;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->ab), cap * sizeof(int2)));
     ctx->ab_cap = cap;
+    return BSPGEMM_OK;
+}
+
+static bspgemm_status ensure_fused(bspgemm_context *ctx, size_t rows)
+{
+    if (rows <= ctx->fused_cap) return BSPGEMM_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->tiles); hipFree(ctx->chain); hipFree(ctx->marks8); hipFree(ctx->tile_count); hipFree(ctx->tile_bound);
+    hipFree(ctx->pack_totals); hipFree(ctx->tickets);
+    ctx->tiles = nullptr; ctx->chain = nullptr; ctx->marks8 = nullptr; ctx->tile_count = nullptr; ctx->tile_bound = nullptr;
+    ctx->pack_totals = nullptr; ctx->tickets = nullptr;
+    ctx->fused_cap = 0;
+    const size_t cap = rows + rows / 8 + 64;               // a tile holds at least one row
+    const size_t blocks = cap / 2048 + 2;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tiles), cap * sizeof(TileDesc)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->chain), cap * sizeof(unsigned long long) + 256));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->marks8), blocks * 256));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tile_count), blocks * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tile_bound), blocks * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->pack_totals), 2 * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tickets), (8 * 32 + 32) * sizeof(unsigned)));
+    ctx->fused_cap = cap;
     return BSPGEMM_OK;
 }
 
@@ -696,6 +731,183 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     return BSPGEMM_OK;
 }
 
+// C rows [row_begin,row_end) of A*B in ONE pass over the products, rows written once at their final
+// place (csrc/tile_rows.inc): products per row -> tiles of consecutive rows -> one persistent kernel
+// that accumulates tile by tile in row order and chains the tiles' sizes by look-back -- the
+// reference's own order of events (final/SpGEMM_mpi_omp.c:28-42: a row is appended where the
+// previous one ended).  Heavy rows (F_i > 2048) are accumulated first, into a workspace bounded by
+// sum(min(F_i, cols)); the chain carries their sizes and they are moved once C.row_ptr exists.
+static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                     int row_begin, int row_end, bspgemm_result **out)
+{
+    if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
+    *out = nullptr;
+    if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int R = row_end - row_begin;
+    hipStream_t s = ctx->stream, sB = ctx->stream_b, sC = ctx->stream_c;
+    if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+    if (bspgemm_status st = ensure_fused(ctx, (size_t)R + 1)) return st;
+    if (bspgemm_status st = ensure_ab(ctx, (size_t)A->nnz + 1)) return st;    // (heavy rows' extents)
+
+    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
+    if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
+    auto bail = [&](bspgemm_status st) {
+        hipStreamSynchronize(s); hipStreamSynchronize(sB); hipStreamSynchronize(sC);
+        bspgemm_result_free(C);
+        return st;
+    };
+    ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
+    bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
+    slot.used = false;
+
+    HIPCHK_B(hipEventRecord(slot.ev[0], s));
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
+
+    // ---- products per row, their prefix, the heavy rows' records, the tiles ------------------------
+    const int scan_tiles = (R + 2047) / 2048;
+    const int heavy_cols = B->cols > 0 ? B->cols : 1;
+    if (bspgemm_status st = ensure_deg8(B)) return bail(st);
+    if (bspgemm_status st = ensure_blk8(B)) return bail(st);
+    launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, row_begin, row_end, ctx->F, s);
+    launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
+    // rows a tile is expected to hold, from the operands' mean row lengths (decides the key width)
+    const double mean_f = (A->rows > 0 && B->rows > 0) ? ((double)A->nnz / A->rows) * ((double)B->nnz / B->rows) : 0.0;
+    const long long est_rows = mean_f >= 1.0 ? (long long)(kTileCap / mean_f + 0.999) : 64;
+    int row_bits = 0, col_bits = 0;
+    const int shape = getenv("BSPGEMM_TILE_SHAPE") ? atoi(getenv("BSPGEMM_TILE_SHAPE")) : 0;
+    const int tile_cap = (shape >= 1 && shape <= 3) ? 1024 : kTileCap;
+    const int levels = tile_levels_for(B->cols, mean_f >= 1.0 ? (long long)(tile_cap / mean_f + 0.999) : 64, tile_cap, &row_bits, &col_bits);
+    const int maxr = (1 << row_bits) > 63 ? 63 : (1 << row_bits);
+    launch_pack_tiles_count(ctx->F, R, tile_cap, maxr, heavy_cols, ctx->marks8, ctx->tile_count, ctx->tile_bound,
+                            ctx->pack_totals, s);
+    launch_pack_tiles_emit(ctx->F, R, tile_cap, maxr, A->d_row_ptr + row_begin, ctx->marks8, ctx->tile_count, ctx->tiles, s);
+    HostScalars *h = ctx->h;
+    HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->heavy_total, ctx->hpartials + scan_tiles, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(h->pack_totals, ctx->pack_totals, 2 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[1], s));
+    HIPCHK_B(hipStreamSynchronize(s));
+    const long long totalF = R > 0 ? h->totalF : 0;
+    if (R == 0) { memset(h->bin_count, 0, sizeof h->bin_count); h->heavy_total = 0; h->pack_totals[0] = h->pack_totals[1] = 0; }
+    const long long ntiles_ll = h->pack_totals[0], bound = h->pack_totals[1];
+    if (ntiles_ll < 0 || ntiles_ll > R) return bail(FAIL(BSPGEMM_ERR_HIP, "tile packer returned an impossible tile count"));
+    const int ntiles = (int)ntiles_ll;
+    if (bspgemm_status st = ensure_tmp(ctx, (size_t)h->heavy_total + 1)) return bail(st);
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(bound)));
+    C->col_cap = bound;
+
+    size_t bin_start[kNumBins + 1] = {0, 0};
+    for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
+    int cls_n[2][kNumBins] = {};
+    // ---- heavy rows: accumulated and read out into the workspace, sizes to cnt[] -------------------
+    const int heavy_bins[2] = {kDenseBin, kMidBin};
+    hipStream_t heavy_lane[2] = {sB, sC};
+    bool any_heavy = false;
+    for (int k = 0; k < 2; k++) any_heavy = any_heavy || h->bin_count[heavy_bins[k]] > 0;
+    if (any_heavy) {
+        HIPCHK_B(hipEventRecord(ctx->ev_tile[0][0], s));
+        for (int k = 0; k < 2; k++) {
+            const int b = heavy_bins[k], n = h->bin_count[b];
+            cls_n[0][b] = n;
+            if (n <= 0) continue;
+            hipStream_t sx = heavy_lane[k];
+            HIPCHK_B(hipStreamWaitEvent(sx, ctx->ev_tile[0][0], 0));
+            const RowRec *rec = ctx->rec + bin_start[b];
+            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
+            launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
+            HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
+                                       row_begin, ctx->tmp, ctx->cnt, sx));
+            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
+            HIPCHK_B(hipEventRecord(ctx->ev_tile[0][1 + k], sx));
+            HIPCHK_B(hipStreamWaitEvent(s, ctx->ev_tile[0][1 + k], 0));
+        }
+    }
+    HIPCHK_B(hipEventRecord(slot.ev[2], s));
+
+    // ---- the tiles ---------------------------------------------------------------------------------
+    if (ntiles > 0) {
+        // chain words: 4 B per tile, then 2 x 8 B per block of 64 tiles
+        const size_t nblk = ((size_t)ntiles + 63) / 64;
+        const size_t bacc_off = (((size_t)ntiles * sizeof(unsigned) + 15) & ~(size_t)15);
+        const size_t chain_bytes = bacc_off + 2 * nblk * sizeof(unsigned long long);
+        HIPCHK_B(hipMemsetAsync(ctx->chain, 0, chain_bytes, s));
+        HIPCHK_B(hipMemsetAsync(ctx->tickets, 0, (8 * 32 + 32) * sizeof(unsigned), s));
+        int grid = tile_rows_grid(levels, ctx->device, shape);
+        if (grid < 1) grid = 1;
+        if (grid > ntiles) grid = ntiles;
+        TileArgs ta;
+        ta.Arow = A->d_row_ptr + row_begin;
+        ta.Acol = A->d_col_idx;
+        ta.Brow = B->d_row_ptr;
+        ta.Bblk = B->blk8_state == 1 ? B->d_blk8 : nullptr;
+        ta.Bcol = B->d_col_idx;
+        ta.tiles = ctx->tiles;
+        ta.ntiles = ntiles;
+        ta.nrows = R;
+        ta.cnt = ctx->cnt;
+        ta.tdesc = reinterpret_cast<unsigned *>(ctx->chain);
+        ta.bacc = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ctx->chain) + bacc_off);
+        ta.binc = ta.bacc + nblk;
+        ta.ticket = ctx->tickets;
+        ta.nshards = grid >= 256 ? 8 : 1;
+        ta.err = ctx->tickets + 8 * 32;
+        ta.row_ptr = C->d_row_ptr;
+        ta.col_idx = C->d_col_idx;
+        ta.col_bits = col_bits;
+        ta.dbg = getenv("BSPGEMM_TILE_DBG") ? atoi(getenv("BSPGEMM_TILE_DBG")) : 0;
+        if (const char *e = getenv("BSPGEMM_TILE_GRID")) { grid = atoi(e); if (grid > ntiles) grid = ntiles; ta.nshards = grid >= 256 ? 8 : 1; }
+        ta.stamps = nullptr;
+        unsigned long long *d_stamps = nullptr;
+        if (getenv("BSPGEMM_TILE_STAMPS")) {
+            HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&d_stamps), 32 * sizeof(unsigned long long)));
+            HIPCHK_B(hipMemsetAsync(d_stamps, 0, 32 * sizeof(unsigned long long), s));
+            ta.stamps = d_stamps;
+        }
+        cls_n[1][1] = ntiles;
+        HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][0], s));
+        HIPCHK_B(launch_tile_rows(levels, ta, grid, shape, s));
+        HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][1], s));
+        HIPCHK_B(hipMemcpyAsync(&h->chain_err, ta.err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        if (d_stamps) {
+            unsigned long long hs[32];
+            HIPCHK_B(hipStreamSynchronize(s));
+            HIPCHK_B(hipMemcpy(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost));
+            hipFree(d_stamps);
+            for (int g = 0; g < 2; g++) {
+                unsigned long long tot = 0;
+                for (int k = 0; k < 12; k++) tot += hs[g * 16 + k];
+                fprintf(stderr, "[tile stamps %s]", g ? "waves>0" : "wave 0 ");
+                for (int k = 0; k < 10; k++) fprintf(stderr, " %d:%.1f%%", k, tot ? 100.0 * hs[g * 16 + k] / tot : 0.0);
+                fprintf(stderr, "  (cycles per tile per wave: %.0f)\n", ntiles ? (double)tot / ntiles : 0.0);
+            }
+        }
+    } else {
+        HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
+        h->chain_err = 0;
+    }
+    HIPCHK_B(hipEventRecord(slot.ev[3], s));
+    for (int k = 0; k < 2; k++) {
+        const int b = heavy_bins[k], n = h->bin_count[b];
+        if (n > 0) launch_place_heavy(ctx->tmp, ctx->rec + bin_start[b], ctx->recpre + bin_start[b], n, C->d_row_ptr, row_begin,
+                                      C->d_col_idx, s);
+    }
+    HIPCHK_B(hipGetLastError());
+    HIPCHK_B(hipMemcpyAsync(&h->nnzC, C->d_row_ptr + R, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipEventRecord(slot.ev[4], s));
+    HIPCHK_B(hipStreamSynchronize(s));
+    if (h->chain_err) return bail(FAIL(BSPGEMM_ERR_HIP, "fused flow: a tile waited more than 4 s for the tiles before it"));
+    if (!getenv("BSPGEMM_TILE_DBG") && (h->nnzC < 0 || h->nnzC > bound)) return bail(FAIL(BSPGEMM_ERR_HIP, "fused flow: more outputs than the bound"));
+    C->nnz = h->nnzC;
+    close_slot(ctx, R, h, totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols));
+    *out = C;
+    return BSPGEMM_OK;
+}
+
 // C = F .* (A*B).  The mask bounds a row (|C_i| <= |F_i|), usually far below its product count, so
 // rows are binned and placed by MASK length in an upper-bound workspace and squeezed together by
 // the compaction kernel once the counts are scanned.
@@ -831,6 +1043,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     // when that does not fit.
     if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
     if (ctx->flow == BSPGEMM_FLOW_EXACT) return multiply_exact(ctx, A, B, row_begin, row_end, out);
+    if (ctx->flow == BSPGEMM_FLOW_FUSED) return multiply_fused(ctx, A, B, row_begin, row_end, out);
     bspgemm_status st = multiply_upper_bound(ctx, A, B, nullptr, row_begin, row_end, out);
     if (st == BSPGEMM_ERR_ALLOC && ctx->flow == BSPGEMM_FLOW_AUTO) {
         (void)hipGetLastError();
@@ -841,7 +1054,7 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
 
 extern "C" bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow)
 {
-    if (!ctx || flow < BSPGEMM_FLOW_AUTO || flow > BSPGEMM_FLOW_EXACT) return FAIL(BSPGEMM_ERR_INVALID, "set_flow");
+    if (!ctx || flow < BSPGEMM_FLOW_AUTO || flow > BSPGEMM_FLOW_FUSED) return FAIL(BSPGEMM_ERR_INVALID, "set_flow");
     ctx->flow = flow;
     return BSPGEMM_OK;
 }

@@ -163,6 +163,53 @@ void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t 
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
                     int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s);
 
+// ---- fused flow: tiles of consecutive rows, one persistent kernel, rows written once -------------
+// a tile = rows [row0, row0 + nrows) of the multiplied range (row0 relative to row_begin)
+struct TileDesc {
+    int row0;
+    unsigned nrf;   // bits 0..7 rows in the tile (1..64), bits 8..27 its products (0 for a heavy row), bit 31 heavy row
+    int a0;         // A.row_ptr[row_begin + row0]
+    int nsrc;       // A-nonzeros of the tile's rows
+};
+constexpr int kTileCap = 2048;           // products per tile = capacity of the workgroup's accumulator
+// rows per tile allowed by the key width: a tile's accumulator holds (local row, column) keys
+int tile_levels_for(int cols, long long est_rows_per_tile, int cap, int *row_bits, int *col_bits);
+// pass 1 of the packer (pack_tiles.hip): marks8 = tile starts, tile_count/bound per 2048 rows,
+// totals[0] = number of tiles, totals[1] = sum of min(F_i, cols); tile_count becomes each block's first tile
+void launch_pack_tiles_count(const long long *F, int n, int cap, int maxr, int cols, unsigned char *marks8,
+                             int *tile_count, long long *bound, long long *totals, hipStream_t s);
+// pass 2: the descriptors (Arow = A.row_ptr + row_begin)
+void launch_pack_tiles_emit(const long long *F, int n, int cap, int maxr, const int *Arow, const unsigned char *marks8,
+                            const int *tile_base, TileDesc *tiles, hipStream_t s);
+struct TileArgs {
+    const int *Arow;            // A.row_ptr + row_begin
+    const int *Acol;
+    const int *Brow;
+    const int *Bblk;            // B's blocked extents table, or NULL: B.row_ptr pairs are gathered
+    const int *Bcol;
+    const TileDesc *tiles;
+    int ntiles;
+    int nrows;                  // rows multiplied (R)
+    const int *cnt;             // |C_i| of the heavy rows (computed before the launch)
+    // the chain (all zeroed before the launch): a tile's size, valid bit on top; per block of 64 tiles an
+    // accumulator (count << 56 | sum) and the inclusive total through the block once somebody knows it
+    unsigned *tdesc;
+    unsigned long long *bacc;
+    unsigned long long *binc;
+    unsigned *ticket;           // tile counters, one per shard, 32 words apart (zeroed before the launch)
+    int nshards;                // 8: tiles dealt round-robin to the XCDs; 1: one counter
+    unsigned *err;              // set when a look-back wait ran out (zeroed before the launch)
+    long long *row_ptr;         // C.row_ptr (R + 1)
+    int *col_idx;               // C.col_idx
+    int col_bits;               // key = (local row << col_bits) | column
+    int dbg;                    // development switches (0 in the product)
+    unsigned long long *stamps; // development (-DBSP_TILE_STAMPS builds): per-phase cycle sums, or NULL
+};
+// persistent kernel: `grid` workgroups; returns hipErrorInvalidValue for an unsupported level count
+hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, int shape, hipStream_t s);
+// workgroups of the tile kernel that fit the device at once (per level count)
+int tile_rows_grid(int levels, int device, int shape);
+
 // int64 row_ptr -> int32 (operand form of a product)
 void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);
 // T = A or I as CSR: row i gets column i appended (duplicates are legal in operands)

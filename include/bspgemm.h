@@ -100,6 +100,7 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
 #define BSPGEMM_FLOW_AUTO        0
 #define BSPGEMM_FLOW_UPPER_BOUND 1
 #define BSPGEMM_FLOW_EXACT       2
+#define BSPGEMM_FLOW_FUSED       3
 bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow);
 
 /* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):

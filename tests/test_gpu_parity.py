@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module", params=["upper-bound", "exact"])
+@pytest.fixture(scope="module", params=["upper-bound", "exact", "fused"])
 def ctx(request):
     """every test of this file runs under both ways from row sizes to C.col_idx (include/bspgemm.h,
     BSPGEMM_FLOW_*): upper-bound placement + compaction, and exact symbolic sizes + emit in place"""
