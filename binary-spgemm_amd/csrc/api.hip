@@ -774,10 +774,8 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
     // rows a tile is expected to hold, from the operands' mean row lengths (decides the key width)
     const double mean_f = (A->rows > 0 && B->rows > 0) ? ((double)A->nnz / A->rows) * ((double)B->nnz / B->rows) : 0.0;
-    const long long est_rows = mean_f >= 1.0 ? (long long)(kTileCap / mean_f + 0.999) : 64;
     int row_bits = 0, col_bits = 0;
-    const int shape = getenv("BSPGEMM_TILE_SHAPE") ? atoi(getenv("BSPGEMM_TILE_SHAPE")) : 0;
-    const int tile_cap = (shape >= 1 && shape <= 3) ? 1024 : kTileCap;
+    const int tile_cap = kTileCap;
     const int levels = tile_levels_for(B->cols, mean_f >= 1.0 ? (long long)(tile_cap / mean_f + 0.999) : 64, tile_cap, &row_bits, &col_bits);
     const int maxr = (1 << row_bits) > 63 ? 63 : (1 << row_bits);
     launch_pack_tiles_count(ctx->F, R, tile_cap, maxr, heavy_cols, ctx->marks8, ctx->tile_count, ctx->tile_bound,
@@ -837,7 +835,7 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
         const size_t chain_bytes = bacc_off + 2 * nblk * sizeof(unsigned long long);
         HIPCHK_B(hipMemsetAsync(ctx->chain, 0, chain_bytes, s));
         HIPCHK_B(hipMemsetAsync(ctx->tickets, 0, (8 * 32 + 32) * sizeof(unsigned), s));
-        int grid = tile_rows_grid(levels, ctx->device, shape);
+        int grid = tile_rows_grid(levels, ctx->device);
         if (grid < 1) grid = 1;
         if (grid > ntiles) grid = ntiles;
         TileArgs ta;
@@ -859,33 +857,11 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
         ta.row_ptr = C->d_row_ptr;
         ta.col_idx = C->d_col_idx;
         ta.col_bits = col_bits;
-        ta.dbg = getenv("BSPGEMM_TILE_DBG") ? atoi(getenv("BSPGEMM_TILE_DBG")) : 0;
-        if (const char *e = getenv("BSPGEMM_TILE_GRID")) { grid = atoi(e); if (grid > ntiles) grid = ntiles; ta.nshards = grid >= 256 ? 8 : 1; }
-        ta.stamps = nullptr;
-        unsigned long long *d_stamps = nullptr;
-        if (getenv("BSPGEMM_TILE_STAMPS")) {
-            HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&d_stamps), 32 * sizeof(unsigned long long)));
-            HIPCHK_B(hipMemsetAsync(d_stamps, 0, 32 * sizeof(unsigned long long), s));
-            ta.stamps = d_stamps;
-        }
         cls_n[1][1] = ntiles;
         HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][0], s));
-        HIPCHK_B(launch_tile_rows(levels, ta, grid, shape, s));
+        HIPCHK_B(launch_tile_rows(levels, ta, grid, s));
         HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][1], s));
         HIPCHK_B(hipMemcpyAsync(&h->chain_err, ta.err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        if (d_stamps) {
-            unsigned long long hs[32];
-            HIPCHK_B(hipStreamSynchronize(s));
-            HIPCHK_B(hipMemcpy(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost));
-            hipFree(d_stamps);
-            for (int g = 0; g < 2; g++) {
-                unsigned long long tot = 0;
-                for (int k = 0; k < 12; k++) tot += hs[g * 16 + k];
-                fprintf(stderr, "[tile stamps %s]", g ? "waves>0" : "wave 0 ");
-                for (int k = 0; k < 10; k++) fprintf(stderr, " %d:%.1f%%", k, tot ? 100.0 * hs[g * 16 + k] / tot : 0.0);
-                fprintf(stderr, "  (cycles per tile per wave: %.0f)\n", ntiles ? (double)tot / ntiles : 0.0);
-            }
-        }
     } else {
         HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
         h->chain_err = 0;
@@ -901,7 +877,7 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
     HIPCHK_B(hipEventRecord(slot.ev[4], s));
     HIPCHK_B(hipStreamSynchronize(s));
     if (h->chain_err) return bail(FAIL(BSPGEMM_ERR_HIP, "fused flow: a tile waited more than 4 s for the tiles before it"));
-    if (!getenv("BSPGEMM_TILE_DBG") && (h->nnzC < 0 || h->nnzC > bound)) return bail(FAIL(BSPGEMM_ERR_HIP, "fused flow: more outputs than the bound"));
+    if (h->nnzC < 0 || h->nnzC > bound) return bail(FAIL(BSPGEMM_ERR_HIP, "fused flow: more outputs than the bound"));
     C->nnz = h->nnzC;
     close_slot(ctx, R, h, totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols));
     *out = C;

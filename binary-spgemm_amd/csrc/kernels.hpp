@@ -202,13 +202,11 @@ struct TileArgs {
     long long *row_ptr;         // C.row_ptr (R + 1)
     int *col_idx;               // C.col_idx
     int col_bits;               // key = (local row << col_bits) | column
-    int dbg;                    // development switches (0 in the product)
-    unsigned long long *stamps; // development (-DBSP_TILE_STAMPS builds): per-phase cycle sums, or NULL
 };
 // persistent kernel: `grid` workgroups; returns hipErrorInvalidValue for an unsupported level count
-hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, int shape, hipStream_t s);
+hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, hipStream_t s);
 // workgroups of the tile kernel that fit the device at once (per level count)
-int tile_rows_grid(int levels, int device, int shape);
+int tile_rows_grid(int levels, int device);
 
 // int64 row_ptr -> int32 (operand form of a product)
 void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);

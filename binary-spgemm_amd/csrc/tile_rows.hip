@@ -41,27 +41,27 @@ int tile_levels_for(int cols, long long est_rows_per_tile, int cap, int *row_bit
     return best_l;
 }
 
-hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, int shape, hipStream_t s)
+hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, hipStream_t s)
 {
     if (grid <= 0 || a.ntiles <= 0) return hipSuccess;
     switch (levels) {
-    case 1: return launch_tile_levels<1>(a, grid, shape, s);
-    case 2: return launch_tile_levels<2>(a, grid, shape, s);
-    case 3: return launch_tile_levels<3>(a, grid, shape, s);
-    case 4: return launch_tile_levels<4>(a, grid, shape, s);
-    case 5: return launch_tile_levels<5>(a, grid, shape, s);
+    case 1: return launch_tile_levels<1>(a, grid, s);
+    case 2: return launch_tile_levels<2>(a, grid, s);
+    case 3: return launch_tile_levels<3>(a, grid, s);
+    case 4: return launch_tile_levels<4>(a, grid, s);
+    case 5: return launch_tile_levels<5>(a, grid, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-int tile_rows_grid(int levels, int device, int shape)
+int tile_rows_grid(int levels, int device)
 {
     switch (levels) {
-    case 1: return tile_levels_grid<1>(device, shape);
-    case 2: return tile_levels_grid<2>(device, shape);
-    case 3: return tile_levels_grid<3>(device, shape);
-    case 4: return tile_levels_grid<4>(device, shape);
-    default: return tile_levels_grid<5>(device, shape);
+    case 1: return tile_levels_grid<1>(device);
+    case 2: return tile_levels_grid<2>(device);
+    case 3: return tile_levels_grid<3>(device);
+    case 4: return tile_levels_grid<4>(device);
+    default: return tile_levels_grid<5>(device);
     }
 }
 

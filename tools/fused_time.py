@@ -7,10 +7,19 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "binary-spgemm_a
 import numpy as np
 import torch  # noqa
 import bspgemm
-flow, scale = sys.argv[1], int(sys.argv[2])
+flow, scale = sys.argv[1], sys.argv[2]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ctx = bspgemm.Context(0)
-rp, ci, n = bspgemm.gen_rmat(scale, 16, (0.30, 0.25, 0.25), seed=1)
+if scale == "validity":      # BASELINE config 1
+    rp, ci, n, _ = bspgemm.readCOO(os.path.join(ROOT, "tests", "golden", "validity_test.mtx"))
+elif scale.startswith("u"):  # uNN: uniform n = 2^NN, d = 16 (u18 = BASELINE config 2)
+    rp, ci, n = bspgemm.gen_uniform(1 << int(scale[1:]), 16, seed=1)
+elif scale.startswith("g"):  # gNN: Graph500-skew R-MAT
+    rp, ci, n = bspgemm.gen_rmat(int(scale[1:]), 16, (0.57, 0.19, 0.19), seed=1)
+elif scale == "powerlaw":    # BASELINE config 5
+    rp, ci, n = bspgemm.gen_powerlaw(1 << 20, 64, 2.1, (1 << 20) // 16, seed=1)
+else:
+    rp, ci, n = bspgemm.gen_rmat(int(scale), 16, (0.30, 0.25, 0.25), seed=1)
 A = ctx.upload(rp, ci, n)
 ctx.set_flow(flow)
 ts = []
@@ -22,6 +31,6 @@ for r in range(reps + 2):
     if r >= 2:
         ts.append((st["ms_total"], st["ms_prepass"], st["ms_count"], st["ms_numeric"], st["ms_stitch"]))
 t = np.median(np.array(ts), axis=0)
-print("%s scale %d env[%s]: total %.3f prepass %.3f count %.3f numeric %.3f stitch %.3f ms  nnz %d  -> %.1f GNZ/s" % (
+print("%s scale %s env[%s]: total %.3f prepass %.3f count %.3f numeric %.3f stitch %.3f ms  nnz %d  -> %.1f GNZ/s" % (
     flow, scale, " ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("BSPGEMM_")), t[0], t[1], t[2], t[3], t[4], nnz, nnz / t[0] / 1e6))
 ctx.close()
