@@ -51,7 +51,7 @@ EXPORTS = [
     "bspgemm_matrix_from_result", "bspgemm_closure",
     "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
     "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
-    "bspgemm_set_flow",
+    "bspgemm_set_flow", "bspgemm_build_info", "bspgemm_matrix_invalidate", "bspgemm_comm_agree", "bspgemm_comm_inject_failure",
 ]
 
 
@@ -146,6 +146,8 @@ def lib():
     L.bspgemm_set_stream.argtypes = [VP, VP]
     L.bspgemm_synchronize.argtypes = [VP]
     L.bspgemm_set_flow.argtypes = [VP, C.c_int]
+    L.bspgemm_build_info.restype = C.c_char_p
+    L.bspgemm_matrix_invalidate.argtypes = [VP]
     L.bspgemm_matrix_upload.argtypes = [VP, C.c_int, C.c_int, VP, VP, PVP]
     L.bspgemm_matrix_wrap_device.argtypes = [VP, C.c_int, C.c_int, C.c_int64, VP, VP, PVP]
     L.bspgemm_matrix_free.argtypes = [VP]

@@ -141,6 +141,12 @@ struct bspgemm_context {
     CachedBuf cache[8] = {};
     size_t cache_budget = 0;            // bytes the cache may pin (a quarter of the device memory)
     int flow = BSPGEMM_FLOW_AUTO;       // bspgemm_set_flow / BSPGEMM_FLOW
+    // environment knobs, read ONCE in bspgemm_create (include/bspgemm.h, "Environment")
+    int class_streams = 2;              // BSPGEMM_CLASS_STREAMS: streams the class launches alternate over (measured: 2 -8 %, 3 no better)
+    bool check = false;                 // BSPGEMM_CHECK: the exact flow never emits on unverified sizes
+    int rw_blk = -1;                    // BSPGEMM_RW_BLK: 0 never / 1 always use the blocked extents table (default: per operand)
+    bool debug_alloc = false;           // BSPGEMM_DEBUG_ALLOC: allocation trace on stderr
+    bool dropin_timing = false;         // BSPGEMM_DROPIN_TIMING: stage times of the int32 drop-ins on stderr
 };
 
 extern "C" int bspgemm_par_max_plus_one(const int *idx, long long n);              // host/par_copy.c
@@ -180,7 +186,7 @@ static bspgemm_status ensure_blk8(const bspgemm_matrix *m)
 {
     if (m->blk8_state) return BSPGEMM_OK;
     m->blk8_state = 2;
-    const int force = getenv("BSPGEMM_RW_BLK") ? atoi(getenv("BSPGEMM_RW_BLK")) : -1;   // 0 never, 1 always (read per operand)
+    const int force = m->ctx->rw_blk;                              // 0 never, 1 always, -1 decide per operand
     if (force == 0 || (force < 0 && m->rows < (1 << 21))) return BSPGEMM_OK;
     const size_t ints = (size_t)3 * (((size_t)m->rows + 7) / 8 + 1);
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_blk8), (ints + 4) * sizeof(int)));
@@ -252,7 +258,12 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     if (const char *e = getenv("BSPGEMM_FLOW"))
         ctx->flow = !strcmp(e, "fused") ? BSPGEMM_FLOW_FUSED : !strcmp(e, "exact") ? BSPGEMM_FLOW_EXACT : (!strcmp(e, "upper-bound") || !strcmp(e, "ub")) ? BSPGEMM_FLOW_UPPER_BOUND
                                                                                                                : BSPGEMM_FLOW_AUTO;
-    if (getenv("BSPGEMM_DEBUG_ALLOC"))
+    if (const char *e = getenv("BSPGEMM_CLASS_STREAMS")) { const int n = atoi(e); ctx->class_streams = n < 1 ? 1 : (n > 3 ? 3 : n); }
+    ctx->check = getenv("BSPGEMM_CHECK") != nullptr;
+    if (const char *e = getenv("BSPGEMM_RW_BLK")) ctx->rw_blk = atoi(e) ? 1 : 0;
+    ctx->debug_alloc = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
+    ctx->dropin_timing = getenv("BSPGEMM_DROPIN_TIMING") != nullptr;
+    if (ctx->debug_alloc)
         fprintf(stderr, "[bspgemm] device %d: %s, %zu MiB, %d CUs; result cache budget %zu MiB\n", device,
                 prop.gcnArchName, (size_t)(prop.totalGlobalMem >> 20), prop.multiProcessorCount, ctx->cache_budget >> 20);
     *out = ctx;
@@ -360,6 +371,25 @@ extern "C" void bspgemm_matrix_free(bspgemm_matrix *m)
     hipFree(m->d_blk8);
     delete m;
 }
+extern "C" bspgemm_status bspgemm_matrix_invalidate(bspgemm_matrix *m)
+{
+    if (!m) return FAIL(BSPGEMM_ERR_INVALID, "matrix is NULL");
+    if (bspgemm_status st = use_device(m->ctx)) return st;
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));          // a multiply may still be reading the tables
+    hipFree(m->d_deg8);
+    hipFree(m->d_blk8);
+    m->d_deg8 = nullptr;
+    m->d_blk8 = nullptr;
+    m->blk8_state = 0;
+    return BSPGEMM_OK;
+}
+
+extern "C" const char *bspgemm_build_info(void)
+{
+    return "libbspgemm: HIP kernels for gfx950 only; flows upper-bound (default), exact, fused; "
+           "timing-only ablation switches: none (BSP_ABLATE=0); tuning constants are compile-time";
+}
+
 extern "C" int bspgemm_matrix_rows(const bspgemm_matrix *m) { return m ? m->rows : 0; }
 extern "C" int bspgemm_matrix_cols(const bspgemm_matrix *m) { return m ? m->cols : 0; }
 extern "C" int64_t bspgemm_matrix_nnz(const bspgemm_matrix *m) { return m ? m->nnz : 0; }
@@ -433,7 +463,13 @@ static bspgemm_status ensure_tmp(bspgemm_context *ctx, size_t ints)
     ctx->tmp = nullptr;
     ctx->tmp_cap = 0;
     const size_t cap = ints + ints / 16 + 1024;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->tmp), cap * sizeof(int)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->tmp), cap * sizeof(int));
+    if (e == hipErrorOutOfMemory) {                     // the cache of freed results may hold what is missing
+        for (auto &c : ctx->cache) if (c.p) { hipFree(c.p); c.p = nullptr; }
+        (void)hipGetLastError();
+        e = hipMalloc(reinterpret_cast<void **>(&ctx->tmp), cap * sizeof(int));
+    }
+    HIPCHK(e);
     ctx->tmp_cap = cap;
     return BSPGEMM_OK;
 }
@@ -460,7 +496,7 @@ static hipError_t result_alloc(bspgemm_context *ctx, void **out, size_t bytes)
         ctx->cache[best].p = nullptr;
         return hipSuccess;
     }
-    static const bool dbg = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
+    const bool dbg = ctx->debug_alloc;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
     if (dbg) {
@@ -485,7 +521,7 @@ static void result_release(bspgemm_context *ctx, void *p, size_t bytes)
     if (!p) return;
     // the cache is capped by BYTES as well as by slots: freed results of a large product must not
     // pin the memory the next one needs (the smallest buffers go first)
-    static const bool dbg = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
+    const bool dbg = ctx->debug_alloc;
     size_t held = 0;
     for (const auto &c : ctx->cache) if (c.p) held += c.bytes;
     if (dbg && held + bytes > ctx->cache_budget)
@@ -525,12 +561,6 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
     return BSPGEMM_OK;
 }
 
-static int class_streams_from_env()
-{
-    int n = 2;                                         // measured: 2 -8 % accumulate time, 3 no better
-    if (const char *e = getenv("BSPGEMM_CLASS_STREAMS")) n = atoi(e);
-    return n < 1 ? 1 : (n > 3 ? 3 : n);
-}
 
 // class launch order of a phase: the heavy rows first (few long-running workgroups: started early
 // they finish under the other classes instead of being the phase's tail), then the one-wave
@@ -603,7 +633,11 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
 
     bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
     if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
-    auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
+    auto bail = [&](bspgemm_status st) {                  // nothing of C may still be written when it is released
+        hipStreamSynchronize(s); hipStreamSynchronize(sB); hipStreamSynchronize(sC);
+        bspgemm_result_free(C);
+        return st;
+    };
     ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
     bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
     slot.used = false;
@@ -634,7 +668,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
     int cls_n[2][kNumBins] = {};
     hipStream_t lanes[3] = {s, sB, sC};
-    const int nlanes = class_streams_from_env();
+    const int nlanes = ctx->class_streams;
     // The class launches of a phase are independent (disjoint rows): they alternate over two streams
     // so that one launch's draining tail overlaps the next one's ramp-up.  The side streams start
     // behind the phase's inputs (fork) and the main stream waits for them at its end (join).
@@ -683,7 +717,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     // without waiting for nnz(C); otherwise the size is read back and exactly that is allocated
     // (F itself when it is within 2 % of nnz(C): the next product of this shape then finds it cached).
     bool synced = false;
-    static const bool check = getenv("BSPGEMM_CHECK") != nullptr;   // development: never emit on unverified sizes
+    const bool check = ctx->check;                         // development: never emit on unverified sizes
     if (!check && result_cached(ctx, result_bytes_colidx(totalF))) {
         HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(totalF)));
         C->col_cap = totalF;
@@ -903,7 +937,11 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
 
     bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
     if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
-    auto bail = [&](bspgemm_status st) { bspgemm_result_free(C); return st; };
+    auto bail = [&](bspgemm_status st) {                  // nothing of C may still be written when it is released
+        hipStreamSynchronize(s); hipStreamSynchronize(sB); hipStreamSynchronize(sC);
+        bspgemm_result_free(C);
+        return st;
+    };
     ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
     bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
     slot.used = false;
@@ -950,7 +988,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     for (int b = 1; b < kNumBins; b++) bin_start[b + 1] = bin_start[b] + (size_t)h->bin_count[b];
     int cls_n[2][kNumBins] = {};
     hipStream_t lanes[3] = {s, sB, sC};
-    const int nlanes = class_streams_from_env();
+    const int nlanes = ctx->class_streams;
     if (R > 0) {
         HIPCHK_B(hipEventRecord(ctx->ev_tile[0][0], s));
         for (int l = 1; l < nlanes; l++) HIPCHK_B(hipStreamWaitEvent(lanes[l], ctx->ev_tile[0][0], 0));
@@ -1295,7 +1333,7 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
     bspgemm_context *ctx;
     if (bspgemm_status st = dropin_ctx(&ctx)) return st;
     const int rows = r1 - r0;
-    const bool timing = getenv("BSPGEMM_DROPIN_TIMING") != nullptr;     // stage times to stderr
+    const bool timing = ctx->dropin_timing;                // stage times to stderr
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     // B's row count is implicit in the reference (never passed): 1 + the largest column of A used
@@ -1409,7 +1447,40 @@ struct bspgemm_comm {
     size_t global_cap = 0;
     long long *d_edges = nullptr;       // global row_ptr at the shard bounds (nranks + 1)
     int *d_bounds = nullptr;            // nranks + 1
+    int *d_status = nullptr;            // 1 + nranks ints: this rank's status, everybody's (bspgemm_comm_agree)
+    double timeout_s = 120.0;           // BSPGEMM_COMM_TIMEOUT_S: a collective that has not completed by then is aborted
+    int inject = 0;                     // bspgemm_comm_inject_failure (tests)
 };
+
+// Waits for the stream behind an RCCL call without trusting it to finish: a peer that died or left the
+// protocol leaves the others inside the collective for ever (the reference's MPI calls have the same
+// property: final/SpGEMM_mpi_omp.c:178-204 checks nothing).  Polls the stream and RCCL's asynchronous
+// error state; on an error or after timeout_s the communicator is aborted and the call FAILS.
+static bspgemm_status comm_wait(bspgemm_comm *c, hipStream_t s, const char *what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return BSPGEMM_OK;
+        if (q != hipErrorNotReady) {
+            snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(q));
+            return BSPGEMM_ERR_HIP;
+        }
+        ncclResult_t async = ncclSuccess;
+        if (c->comm && ncclCommGetAsyncError(c->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            snprintf(g_err, sizeof g_err, "%s: RCCL reported %s; communicator aborted", what, ncclGetErrorString(async));
+            ncclCommAbort(c->comm);
+            c->comm = nullptr;
+            return BSPGEMM_ERR_COMM;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+            snprintf(g_err, sizeof g_err, "%s: no completion after %.0f s (a peer is missing?); communicator aborted", what, c->timeout_s);
+            if (c->comm) { ncclCommAbort(c->comm); c->comm = nullptr; }
+            return BSPGEMM_ERR_COMM;
+        }
+        usleep(200);
+    }
+}
 
 extern "C" bspgemm_status bspgemm_comm_unique_id(unsigned char id[BSPGEMM_UNIQUE_ID_BYTES])
 {
@@ -1432,6 +1503,8 @@ static bspgemm_status comm_new(bspgemm_context *ctx, int rank, int nranks, bspge
     c->nranks = nranks;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_edges), ((size_t)nranks + 1) * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_bounds), ((size_t)nranks + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_status), ((size_t)nranks + 1) * sizeof(int));
+    if (const char *t = getenv("BSPGEMM_COMM_TIMEOUT_S")) { const double v = atof(t); if (v > 0) c->timeout_s = v; }
     if (e != hipSuccess) {
         bspgemm_comm_destroy(c);
         snprintf(g_err, sizeof g_err, "comm buffers: %s", hipGetErrorString(e));
@@ -1497,7 +1570,45 @@ extern "C" void bspgemm_comm_destroy(bspgemm_comm *c)
     hipFree(c->d_global);
     hipFree(c->d_edges);
     hipFree(c->d_bounds);
+    hipFree(c->d_status);
     delete c;
+}
+
+extern "C" void bspgemm_comm_inject_failure(bspgemm_comm *c, int what) { if (c) c->inject = what; }
+
+// Every rank contributes its status; everybody gets the worst.  Called before a collective that a failed
+// rank would not enter: either all ranks go in, or none does (a rank that left the protocol alone leaves
+// the others blocked in ncclSend / MPI_Gatherv for ever).  Collective.
+extern "C" bspgemm_status bspgemm_comm_agree(bspgemm_comm *c, bspgemm_status mine)
+{
+    if (!c) return FAIL(BSPGEMM_ERR_INVALID, "comm is NULL");
+    bspgemm_context *ctx = c->ctx;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    hipStream_t s = ctx->stream;
+    const int n = c->nranks;
+    int worst = (int)mine;
+    if (c->comm) {
+        const int v = (int)mine;
+        HIPCHK(hipMemcpyAsync(c->d_status, &v, sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        NCCLCHK(ncclAllGather(c->d_status, c->d_status + 1, 1, ncclInt32, c->comm, s));
+        if (bspgemm_status st = comm_wait(c, s, "status all-gather")) return st;
+        int all[1025];
+        if (n > 1024) return FAIL(BSPGEMM_ERR_INVALID, "more than 1024 ranks");
+        HIPCHK(hipMemcpy(all, c->d_status + 1, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        for (int r = 0; r < n; r++) if (all[r] > worst) worst = all[r];
+    } else {
+        const int v = (int)mine;
+        int *all = static_cast<int *>(malloc((size_t)n * sizeof(int)));
+        if (!all) return FAIL(BSPGEMM_ERR_ALLOC, "status staging");
+        const int rc = c->host.allgather(c->host.user, &v, all, sizeof(int));
+        if (rc == 0) for (int r = 0; r < n; r++) if (all[r] > worst) worst = all[r];
+        free(all);
+        if (rc != 0) return FAIL(BSPGEMM_ERR_COMM, "host all-gather failed");
+    }
+    if (worst != BSPGEMM_OK && mine == BSPGEMM_OK)
+        snprintf(g_err, sizeof g_err, "another rank failed with status %d (%s)", worst, bspgemm_status_string((bspgemm_status)worst));
+    return (bspgemm_status)worst;
 }
 
 extern "C" int bspgemm_comm_rank(const bspgemm_comm *c) { return c ? c->rank : -1; }
@@ -1531,6 +1642,7 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
 {
     if (!c || !local || !bounds || !d_row_ptr_global) return FAIL(BSPGEMM_ERR_INVALID, "stitch_row_ptr");
     if (bspgemm_status st = comm_bounds_ok(c, bounds)) return st;
+    if (c->nranks > 1024) return FAIL(BSPGEMM_ERR_INVALID, "more than 1024 ranks");
     const int my_rows = bounds[c->rank + 1] - bounds[c->rank];
     if (my_rows != local->rows) return FAIL(BSPGEMM_ERR_INVALID, "local result does not match bounds[rank]");
     bspgemm_context *ctx = c->ctx;
@@ -1564,6 +1676,7 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
     // 2. the one collective
     if (c->comm) {
         NCCLCHK(ncclAllGather(c->d_send, c->d_recv, (size_t)width, ncclInt32, c->comm, s));
+        if (bspgemm_status st = comm_wait(c, s, "row-length all-gather")) return st;
     } else {
         const size_t bytes = (size_t)width * sizeof(int);
         int *hs = static_cast<int *>(malloc(bytes)), *hr = static_cast<int *>(malloc(bytes * c->nranks));
@@ -1586,7 +1699,6 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
         hipLaunchKernelGGL(k_pick_edges, dim3(1), dim3(c->nranks + 1 <= 1024 ? c->nranks + 1 : 1024), 0, s,
                            c->d_global, c->d_bounds, c->nranks + 1, c->d_edges);
         long long edges[1025];
-        if (c->nranks > 1024) return FAIL(BSPGEMM_ERR_INVALID, "more than 1024 ranks");
         HIPCHK(hipMemcpyAsync(edges, c->d_edges, ((size_t)c->nranks + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         for (int r = 0; r < c->nranks; r++) shard_nnz[r] = edges[r + 1] - edges[r];
@@ -1609,7 +1721,10 @@ extern "C" bspgemm_status bspgemm_comm_gather_col_idx(bspgemm_comm *c, const bsp
     hipStream_t s = ctx->stream;
     long long total = 0;
     for (int r = 0; r < c->nranks; r++) total += shard_nnz[r];
-    if (c->rank == root && total > 0 && !col_idx_host) return FAIL(BSPGEMM_ERR_INVALID, "root needs a destination");
+    // A root WITHOUT a destination (its malloc failed) still runs the whole collective -- the peers are already
+    // committed to it -- and reports the failure afterwards: an early return here left them blocked in ncclSend /
+    // MPI_Gatherv.  (SpGEMM_hip_multi agrees on the status first, so this is the second line of defence.)
+    const bool root_blind = c->rank == root && total > 0 && !col_idx_host;
     if (c->comm) {
         int *d_all = nullptr;
         if (c->rank == root)
@@ -1631,11 +1746,13 @@ extern "C" bspgemm_status bspgemm_comm_gather_col_idx(bspgemm_comm *c, const bsp
             snprintf(g_err, sizeof g_err, "col_idx gather: %s", ncclGetErrorString(nr));
             st = BSPGEMM_ERR_COMM;
         }
-        if (!st && c->rank == root && total > 0 &&
+        if (!st) st = comm_wait(c, s, "col_idx gather");
+        if (!st && c->rank == root && total > 0 && !root_blind &&
             hipMemcpyAsync(col_idx_host, d_all, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)
             st = FAIL(BSPGEMM_ERR_HIP, "gathered col_idx to host");
         if (hipStreamSynchronize(s) != hipSuccess && !st) st = FAIL(BSPGEMM_ERR_HIP, "sync");
         if (d_all) result_release(ctx, d_all, result_bytes_colidx(total));
+        if (!st && root_blind) st = FAIL(BSPGEMM_ERR_INVALID, "root has no destination (the gather was run and discarded)");
         return st;
     }
     if (!c->host.gatherv) return FAIL(BSPGEMM_ERR_INVALID, "host transport has no gatherv");
@@ -1647,8 +1764,12 @@ extern "C" bspgemm_status bspgemm_comm_gather_col_idx(bspgemm_comm *c, const bsp
         if (!bytes) st = FAIL(BSPGEMM_ERR_ALLOC, "counts");
         else {
             for (int r = 0; r < c->nranks; r++) bytes[r] = (size_t)shard_nnz[r] * sizeof(int);
-            if (c->host.gatherv(c->host.user, mine, (size_t)local->nnz * sizeof(int), col_idx_host, bytes, root) != 0)
+            int *scratch = nullptr;                          // a blind root receives into scratch and discards
+            if (root_blind) scratch = static_cast<int *>(malloc((size_t)total * sizeof(int)));
+            if (c->host.gatherv(c->host.user, mine, (size_t)local->nnz * sizeof(int), root_blind ? scratch : col_idx_host, bytes, root) != 0)
                 st = FAIL(BSPGEMM_ERR_COMM, "host gatherv failed");
+            free(scratch);
+            if (!st && root_blind) st = FAIL(BSPGEMM_ERR_INVALID, "root has no destination (the gather was run and discarded)");
             free(bytes);
         }
     }
@@ -1681,22 +1802,25 @@ extern "C" int SpGEMM_hip_multi(bspgemm_comm *c, int *Acol, int *Arow, int An, i
         if (!st) st = bspgemm_matrix_upload(ctx, brows, Bm, Brow, Bcol, &B);
         if (!st) st = bspgemm_partition_rows(ctx, A, B, c->nranks, bounds);
         if (!st) st = bspgemm_multiply(ctx, A, B, bounds[c->rank], bounds[c->rank + 1], &C);
+        // from here on the ranks act together: nobody enters a collective unless everybody does
+        st = bspgemm_comm_agree(c, st);
         const int64_t *d_global = nullptr;
         if (!st) st = bspgemm_comm_stitch_row_ptr(c, C, bounds, &d_global, shard);
+        st = bspgemm_comm_agree(c, st);
         long long total = 0;
         if (!st) {
             for (int r = 0; r < c->nranks; r++) total += shard[r];
             if (total > INT_MAX) st = FAIL(BSPGEMM_ERR_OVERFLOW, "nnz(C) > INT_MAX: use the int64 handle API");
         }
         if (!st && c->rank == 0) {
-            dst = static_cast<int *>(malloc((size_t)(total > 0 ? total : 1) * sizeof(int)));
+            if (c->inject != 1) dst = static_cast<int *>(malloc((size_t)(total > 0 ? total : 1) * sizeof(int)));
             rp64 = static_cast<int64_t *>(malloc(((size_t)An + 1) * sizeof(int64_t)));
             if (!dst || !rp64) st = FAIL(BSPGEMM_ERR_ALLOC, "host result");
         }
-        // (a root that failed to allocate still takes part in the gather so that no rank hangs)
-        bspgemm_status gst = BSPGEMM_OK;
-        if (C && d_global && total <= INT_MAX) gst = bspgemm_comm_gather_col_idx(c, C, shard, 0, dst);
-        if (!st) st = gst;
+        // the root's allocation is the last thing that can fail on one rank only: agreed on before the gather, so
+        // that either every rank enters it or none does
+        st = bspgemm_comm_agree(c, st);
+        if (!st) st = bspgemm_comm_gather_col_idx(c, C, shard, 0, dst);
         if (!st && c->rank == 0) {
             if (hipMemcpy(rp64, d_global, ((size_t)An + 1) * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
                 st = FAIL(BSPGEMM_ERR_HIP, "row_ptr to host");

@@ -25,44 +25,21 @@ namespace bsp {
 //        rows with thousands of products, which one workgroup per CU serialises phase by phase
 //        (256 threads: the same four rows in flight with half the waves to cover their latencies).
 constexpr int kDenseThreadsBig = 1024;
-#ifndef BSP_MID_THREADS
-#define BSP_MID_THREADS 512
-#endif
-#ifndef BSP_MID_MINW
-#define BSP_MID_MINW 8               // four 8-wave workgroups per CU: 64 VGPRs
-#endif
-constexpr int kDenseThreadsMid = BSP_MID_THREADS;
-#ifndef BSP_BIG_WORDS
-#define BSP_BIG_WORDS 16384
-#endif
-#ifndef BSP_BIG_MINW
-#define BSP_BIG_MINW 4
-#endif
-constexpr int kDenseMaxWords = BSP_BIG_WORDS;  // 64-bit words per window = 2^20 columns = 128 KiB
-#ifndef BSP_MID_WORDS
-#define BSP_MID_WORDS 4096
-#endif
-constexpr int kMidMaxWords = BSP_MID_WORDS;  // 4096 words = 2^18 columns = 32 KiB
+constexpr int kDenseThreadsMid = 512;
+constexpr int kMidMinWaves = 8;              // four 8-wave workgroups per CU: 64 VGPRs
+constexpr int kBigMinWaves = 4;
+constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
+constexpr int kMidMaxWords = 4096;           // 4096 words = 2^18 columns = 32 KiB
 constexpr int kDenseWordBits = 12;           // 64-column words with at least this many outputs are emitted by a whole wave
-#ifndef BSP_DENSE_TILE_PER_THREAD
-#define BSP_DENSE_TILE_PER_THREAD 32         // products per thread and tile (multiple of 4: one wave scans the tile's words)
-#endif
-#ifndef BSP_DENSE_INFLIGHT
-#define BSP_DENSE_INFLIGHT 8
-#endif
-#ifndef BSP_DENSE_NOEMIT             // timing only: 1 = counts kept, nothing emitted; 2 = loops run, stores dropped
-#define BSP_DENSE_NOEMIT 0
-#endif
-#ifndef BSP_DENSE_ABLATE             // timing only (WRONG results): 1 no window atomics, 2 + no B.col_idx loads, 3 + no read-out
-#define BSP_DENSE_ABLATE 0
-#endif
+constexpr int kDenseTilePerThread = 32;      // products per thread and tile (multiple of 4: one wave scans the tile's words)
+constexpr int kDenseInFlight = 8;            // B.col_idx loads a thread keeps in flight
 
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
 // holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
 // set in P is set in K, and K is what gets read out.
 template <bool MASKED, int kDenseThreads>
-__global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? BSP_BIG_MINW : BSP_MID_MINW)) void k_dense_rows(const int2 *__restrict__ ab,
+__global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? kBigMinWaves : kMidMinWaves)) void k_dense_rows(const int2 *__restrict__ ab,
                                                               const int *__restrict__ Bcol,
                                                               int cols, int wwords,
                                                               const RowRec *__restrict__ rec,
@@ -80,9 +57,9 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     u64 *bm = MASKED ? bmP + wwords : bmP;                             // what is read out (K or P)
     u32 *bmK32 = reinterpret_cast<u32 *>(bm);
     constexpr int kWaves = kDenseThreads / 64;
-    constexpr int kTile = kDenseThreads * BSP_DENSE_TILE_PER_THREAD;   // products per tile
+    constexpr int kTile = kDenseThreads * kDenseTilePerThread;   // products per tile
     constexpr int kTileWords = kTile / 32;
-    constexpr int kInFlight = BSP_DENSE_INFLIGHT;                      // B.col_idx loads a thread keeps in flight
+    constexpr int kInFlight = kDenseInFlight;                      // B.col_idx loads a thread keeps in flight
     static_assert(kTileWords % 64 == 0 && kTileWords <= kDenseThreads, "one wave scans the tile's words, blocked");
     __shared__ int wtot[kWaves], wcnt[kWaves];
     __shared__ long long wsum[kWaves];
@@ -105,9 +82,6 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     // they then start at the loads -- no extents, no block scan, no tile bitmap, none of their barriers
     // (on a wide matrix most rows of the small shape are like that, and each of these phases is a
     // latency the row's few waves cannot hide).
-#ifndef BSP_DENSE_KEEP_PLAN
-#define BSP_DENSE_KEEP_PLAN 1
-#endif
     long long PB = 0;
     bool plan_kept = false;                                            // uniform
     for (int win = 0; win < nwin; win++) {
@@ -186,18 +160,17 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                     int cv[kInFlight];
 #pragma unroll
                     for (int u = 0; u < kInFlight; u++)
-                        cv[u] = ok[u] ? (BSP_DENSE_ABLATE >= 2 ? addr[u] : Bcol[addr[u]]) : -1;
+                        cv[u] = ok[u] ? Bcol[addr[u]] : -1;
 #pragma unroll
                     for (int u = 0; u < kInFlight; u++) {
                         const u32 c = (u32)(cv[u] - lo32);                 // columns below the window wrap to huge values
-                        if (BSP_DENSE_ABLATE >= 1) { if (ok[u] && c == 0xfffffff0u) bm32[0] = 1u; }
-                        else if (ok[u] && c < (u32)W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                        if (ok[u] && c < (u32)W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
                     }
                 }
             }
             __syncthreads();
         }
-        if (BSP_DENSE_KEEP_PLAN && win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && PB <= kTile && PB > 0;
+        if (win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && PB <= kTile && PB > 0;
         if (MASKED) {
             // keep the product bits that F's row admits, then wipe P for the next window / row
             const int f0 = Frow[i], f1 = Frow[i + 1];
@@ -214,17 +187,13 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
         // outputs are one contiguous piece of the row, the step's pieces follow each other.  kWpl = 4:
         // ONE wave scan per 256 words (it was one per 64: in a window that is mostly empty -- a row with a
         // few thousand products over 2^18 columns -- the scans were two thirds of the kernel's VALU work).
-#ifndef BSP_DENSE_WPL
-#define BSP_DENSE_WPL 4
-#endif
-        constexpr int kWpl = BSP_DENSE_WPL;
+        constexpr int kWpl = 4;
         constexpr int kStepWords = 64 * kWpl;
         constexpr int kWavesPerWg = kDenseThreads / 64;
         const int wpw = ((wwords + kWavesPerWg - 1) / kWavesPerWg + kStepWords - 1) / kStepWords * kStepWords;
         const int wbeg = wave * wpw;
         const int wend = (wbeg + wpw < wwords) ? wbeg + wpw : wwords;
         int c = 0;
-        if (BSP_DENSE_ABLATE < 3)
         for (int w = wbeg + lane; w < wend; w += 64) c += __popcll(bm[w]);
         const int inc = wave_incl_scan(c);
         if (lane == 63) wtot[wave] = inc;
@@ -236,7 +205,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             btotal += t;
         }
         int run = total + off;                                 // wave-uniform output cursor
-        for (int w0 = wbeg; w0 < (BSP_DENSE_ABLATE >= 3 ? wbeg : wend); w0 += kStepWords) {
+        for (int w0 = wbeg; w0 < wend; w0 += kStepWords) {
             const int wl = w0 + kWpl * lane;                   // this lane's first word
             u64 m[kWpl];
             int cw = 0;
@@ -264,17 +233,14 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                     const u64 mw = wave_bcast64(m[k], src);
                     const int pw = wave_bcast(pos, src);
                     const int bw = wave_bcast(base, src) + 64 * k;
-                    if (BSP_DENSE_NOEMIT != 2 && ((mw >> lane) & 1ull)) out[pw + __popcll(mw & mask_lt(lane))] = bw | lane;
+                    if ((mw >> lane) & 1ull) out[pw + __popcll(mw & mask_lt(lane))] = bw | lane;
                 }
-                u64 mk = (ck >= kDenseWordBits || BSP_DENSE_NOEMIT == 1) ? 0ull : m[k];
+                u64 mk = (ck >= kDenseWordBits) ? 0ull : m[k];
                 int p = pos;
-                int sinkv = 0;
                 while (mk) {
-                    if (BSP_DENSE_NOEMIT == 2) sinkv ^= ((base + 64 * k) | (int)__builtin_ctzll(mk)) + p++;
-                    else out[p++] = (base + 64 * k) | (int)__builtin_ctzll(mk);
+                    out[p++] = (base + 64 * k) | (int)__builtin_ctzll(mk);
                     mk &= mk - 1ull;
                 }
-                if (BSP_DENSE_NOEMIT == 2 && sinkv == 0x7fffffff) out[0] = sinkv;
                 pos += ck;
             }
             run += step_total;
@@ -339,13 +305,7 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
 constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup (a small product gets smaller chunks: see launch_compact)
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
-#ifndef BSP_COMPACT_NOSLOW
-#define BSP_COMPACT_NOSLOW 0     // timing-only: 1 drops the groups that straddle a row boundary (WRONG results)
-#endif
-#ifndef BSP_COMPACT_INFLIGHT
-#define BSP_COMPACT_INFLIGHT 4
-#endif
-constexpr int kCompactInFlight = BSP_COMPACT_INFLIGHT;   // 16-B groups a thread has in flight
+constexpr int kCompactInFlight = 4;      // 16-B groups a thread has in flight (8 measured slower)
 constexpr int kCompactSparseRows = 4096; // a chunk spanning more rows than this is searched per output
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
@@ -437,7 +397,7 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                 if (fast[u]) {
                     const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
                     __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
-                } else if (live[u] && !BSP_COMPACT_NOSLOW) {
+                } else if (live[u]) {
                     int r = lo_r[u];
                     for (int e = 0; e < 4; e++) {
                         const long long oe = o[u] + e;

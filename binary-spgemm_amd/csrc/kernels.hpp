@@ -1,7 +1,7 @@
 // kernels.hpp -- launch wrappers of the HIP kernels behind bspgemm_multiply (host-callable).
 // Kernel bodies: prepass.hip (row work, scans, class records), wave_rows.inc (+ wave_rows_L*.hip),
-// wave_masked.hip, dense_rows.hip (heavy rows + compaction).  BSP_* macros are A/B switches for
-// tools/variants.sh; the defaults are the shipped configuration.
+// wave_masked.hip, dense_rows.hip (heavy rows + compaction), pack_tiles.hip + tile_rows.inc (fused flow).
+// Tuning constants are compile-time constants, not switches: what was tried against them is in profiles/.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,25 +29,15 @@ constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
 // the rows it is good for.  Swept with BSPGEMM_MID_CAP on the round-2 build (numeric phase, ms):
 // Graph500-skew scale 18 (one pass) 131072: 6.47, 524288: 5.87, 4194304: 6.18; power-law n = 2^20 (four
 // passes) 8192: 13.18, 32768: 12.88, 131072: 12.59, 262144: 12.96 -- i.e. 524288 / passes in both cases.
-#ifndef BSP_MID_CAP1
-#define BSP_MID_CAP1 524288
-#endif
-#ifndef BSP_MID_CAPN
-#define BSP_MID_CAPN 524288
-#endif
+constexpr int kMidCap = 524288;
 inline int mid_cap_for_cols(long long cols)
 {
-    static const long long forced = getenv("BSPGEMM_MID_CAP") ? atoll(getenv("BSPGEMM_MID_CAP")) : 0;   // tuning knob
-    if (forced > 0) return forced < kMaxWaveCap ? kMaxWaveCap : (int)forced;
     const long long passes = (cols + (1ll << 18) - 1) >> 18;
-    if (passes <= 1) return BSP_MID_CAP1;
-    const long long c = BSP_MID_CAPN / passes;
+    if (passes <= 1) return kMidCap;
+    const long long c = kMidCap / passes;
     return c < kMaxWaveCap ? kMaxWaveCap : (int)c;      // (== kMaxWaveCap: no row takes the small shape)
 }
-#ifndef BSP_RPW
-#define BSP_RPW 16
-#endif
-constexpr int kRowsPerWave = BSP_RPW;         // consecutive list entries handled by one wave
+constexpr int kRowsPerWave = 16;        // consecutive list entries handled by one wave
 
 constexpr int kWaveTopWords = 256;      // 32-bit words of the directly addressed top bitmap
 
@@ -66,14 +56,11 @@ inline int levels_for_cols(int64_t cols)
 // three levels): one ranked level costs two LDS reads, an atomic and a blocked scan per product
 // chunk, the larger top only a longer scan/clear per row (measured at 2^24 columns: -6 % kernel
 // time; 1024 words at 2^25 columns loses to four levels: too few resident waves).
-#ifndef BSP_WIDE_TOP
-#define BSP_WIDE_TOP 1
-#endif
 constexpr int kWaveTopWordsWide = 512;
 inline int wave_levels_for_cols(int64_t cols)
 {
     const int L = levels_for_cols(cols);
-    if (BSP_WIDE_TOP && L == 4 && cols <= ((int64_t)kWaveTopWordsWide << 15)) return 3;
+    if (L == 4 && cols <= ((int64_t)kWaveTopWordsWide << 15)) return 3;
     return L;
 }
 

@@ -22,18 +22,13 @@ namespace bsp {
 
 struct __attribute__((packed, aligned(4))) Int2U { int x, y; };   // 8 B, only dword aligned
 
-#ifndef BSP_RW_UNROLL
-#define BSP_RW_UNROLL 4
-#endif
-#ifndef BSP_RW_LONG_ROW
-#define BSP_RW_LONG_ROW 256
-#endif
 // A wave holds 8 rows, 8 lanes each.  Rows of more than kLongRow nonzeros are first swept by ALL 64
 // lanes, one row at a time (a hub row of 36000 nonzeros was 1136 dependent trips of its 8 lanes: the
 // whole prepass of a power-law input waited for it); the others by their own 8 lanes.  `sweep(first, end,
 // stride)` handles nonzeros first, first+stride, ... and returns the lane's partial sum; the result is the
 // row's sum in the row's lane 0 (sub == 0).
-constexpr int kLongRow = BSP_RW_LONG_ROW;
+constexpr int kLongRow = 256;
+constexpr int kRowWorkUnroll = 4;            // nonzeros per lane and trip (independent gathers in flight)
 template <typename Sweep>
 __device__ __forceinline__ long long rows_of_a_wave(int a0, int a1, int sub, Sweep &&sweep)
 {
@@ -74,7 +69,7 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
     if (r < nrows) { a0 = Arow[row_begin + r]; a1 = Arow[row_begin + r + 1]; }
     // U nonzeros per lane and trip: their A.col_idx loads, then their B.row_ptr gathers, are
     // issued together (independent misses in flight instead of one dependent chain per nonzero)
-    constexpr int U = BSP_RW_UNROLL;
+    constexpr int U = kRowWorkUnroll;
     auto sweep = [&](long long first, long long end, int stride) {
         long long sum = 0;
         for (long long jj = first; jj < end; jj += (long long)stride * U) {   // 64-bit: jj + stride*u may pass INT_MAX
@@ -159,7 +154,7 @@ __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Ar
     const int sub = (int)(gid & 7);
     int a0 = 0, a1 = 0;
     if (r < nrows) { a0 = Arow[row_begin + r]; a1 = Arow[row_begin + r + 1]; }
-    constexpr int U = BSP_RW_UNROLL;
+    constexpr int U = kRowWorkUnroll;
     auto sweep = [&](long long first, long long end, int stride) {
         long long sum = 0;
         for (long long jj = first; jj < end; jj += (long long)stride * U) {

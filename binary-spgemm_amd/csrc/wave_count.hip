@@ -26,9 +26,7 @@ constexpr int pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 constexpr int log2_of(int p) { int l = 0; while ((1 << l) < p) l++; return l; }
 
 // hash slots per product of capacity, as a fraction (the table is the next power of two)
-#ifndef BSP_COUNT_NUM
 #define BSP_COUNT_NUM 3
-#endif
 
 template <int CHUNKS>
 struct CountCfg {

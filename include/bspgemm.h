@@ -45,6 +45,9 @@ typedef enum bspgemm_status {
 const char *bspgemm_status_string(bspgemm_status s);
 /* text of the last failure on this thread (HIP error string, file:line) */
 const char *bspgemm_last_error(void);
+/* what this build of the library contains (one line of text).  The shipped library has no
+ * timing-only ablation paths: tests/test_abi.py asserts "BSP_ABLATE=0" here.                 */
+const char *bspgemm_build_info(void);
 
 /* ---------------------------------------------------------------- native handle API ---
  * Replaces, with device-resident operands and int64 row_ptr, the call
@@ -53,6 +56,17 @@ const char *bspgemm_last_error(void);
  * final/utils.c:159-173, which has no GPU counterpart: rows are emitted in order).
  * Upload once, multiply `times` times, download if wanted -- the reference's timed region
  * (:320-324) likewise excludes I/O and CSR construction.                                     */
+/* Threads: a bspgemm_context is NOT thread-safe -- it owns one set of workspaces, one pinned block
+ * of read-back scalars and the timing slots of its last 16 multiplies; calls on one context must
+ * be serialised by the caller (different contexts, also on one device, are independent).  The
+ * int32 drop-ins share one process-wide context behind a mutex.
+ * Memory: results freed with bspgemm_result_free go to a per-context cache (at most 8 buffers and a
+ * quarter of the device memory) and are handed to the next multiply instead of hipMalloc; the
+ * default flow additionally keeps a workspace of F entries (F = products), i.e. about 2F ints live
+ * per context after a multiply (10.7 GB for BASELINE config 3).  bspgemm_destroy releases all.
+ * Environment (read once, in bspgemm_create): BSPGEMM_FLOW=auto|upper-bound|exact|fused,
+ * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_DEBUG_ALLOC,
+ * BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.                             */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
 typedef struct bspgemm_result  bspgemm_result;    /* device-resident CSR product, int64 row_ptr */
@@ -70,10 +84,17 @@ bspgemm_status bspgemm_synchronize(bspgemm_context *ctx);
 bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, int cols,
                                      const int *row_ptr, const int *col_idx,
                                      bspgemm_matrix **out);
-/* Adopt device arrays the caller owns (not freed by bspgemm_matrix_free), row_ptr[0] == 0.   */
+/* Adopt device arrays the caller owns (not freed by bspgemm_matrix_free), row_ptr[0] == 0.
+ * An operand is IMMUTABLE while the handle lives: the library keeps tables derived from row_ptr
+ * (row lengths by the byte, blocked extents) and builds them on first use.  A caller that rewrites
+ * the wrapped arrays in place must call bspgemm_matrix_invalidate before the next multiply; a
+ * stale table would size rows from old lengths.                                                */
 bspgemm_status bspgemm_matrix_wrap_device(bspgemm_context *ctx, int rows, int cols, int64_t nnz,
                                           const int *d_row_ptr, const int *d_col_idx,
                                           bspgemm_matrix **out);
+/* drops the derived tables of an operand (they are rebuilt on the next use); synchronises the
+ * context's stream first                                                                        */
+bspgemm_status bspgemm_matrix_invalidate(bspgemm_matrix *m);
 void    bspgemm_matrix_free(bspgemm_matrix *m);
 int     bspgemm_matrix_rows(const bspgemm_matrix *m);
 int     bspgemm_matrix_cols(const bspgemm_matrix *m);
@@ -95,7 +116,12 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
  *   EXACT        a symbolic pass sizes every row exactly first (hash-set count kernels), C.row_ptr
  *                is their scan, and the numeric pass emits every row at its final place: nnz(C)
  *                entries, no F-sized workspace.
- *   AUTO         (default, or env BSPGEMM_FLOW=auto|upper-bound|exact) UPPER_BOUND, and EXACT when
+ *   FUSED        rows are accumulated in ROW ORDER by tiles of consecutive rows in one persistent kernel;
+ *                a tile's place is the total of the tiles before it (look-back chain), every row is
+ *                written once, at its final place: no workspace, no count pass -- the reference's own
+ *                order of events (final/SpGEMM_mpi_omp.c:28-42).  Opt-in: measured slower than the
+ *                other two on large products.
+ *   AUTO         (default, or env BSPGEMM_FLOW=auto|upper-bound|exact|fused) UPPER_BOUND, and EXACT when
  *                its buffers cannot be allocated.                                               */
 #define BSPGEMM_FLOW_AUTO        0
 #define BSPGEMM_FLOW_UPPER_BOUND 1
@@ -154,7 +180,7 @@ typedef struct bspgemm_stats {
     int64_t bytes_read_alg;  /* its HBM-read part: bytes_alg - 4nnzC - 8(rows+1)             */
     int64_t rows_per_bin[BSPGEMM_MAX_BINS]; /* rows per capacity class: [0] empty rows,
                                 [1..bins-3] one-wavefront rows with at most bin_cap[b] products,
-                                [bins-2], [bins-1] heavy rows (one 256- / 1024-thread workgroup
+                                [bins-2], [bins-1] heavy rows (one 512- / 1024-thread workgroup
                                 each); rest unused                                           */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* = ms_prepass + ms_count: everything that sizes C.row_ptr     */
@@ -243,6 +269,14 @@ typedef struct bspgemm_host_transport {
 bspgemm_status bspgemm_comm_create_host(bspgemm_context *ctx, const bspgemm_host_transport *transport,
                                         int rank, int nranks, bspgemm_comm **comm);
 void           bspgemm_comm_destroy(bspgemm_comm *comm);
+/* Collective: every rank passes its own status, every rank gets the worst one.  Run it before a
+ * collective that a failed rank would skip -- a rank that leaves the protocol alone leaves the others
+ * blocked (the reference's MPI_Gather/Gatherv, final/SpGEMM_mpi_omp.c:178-204, have no such guard).
+ * Every RCCL wait of this library is bounded (env BSPGEMM_COMM_TIMEOUT_S, default 120): on a timeout
+ * or an asynchronous RCCL error the communicator is aborted and the call returns BSPGEMM_ERR_COMM.  */
+bspgemm_status bspgemm_comm_agree(bspgemm_comm *comm, bspgemm_status mine);
+/* test hook: 1 = the next SpGEMM_hip_multi on rank 0 behaves as if its host allocation had failed */
+void           bspgemm_comm_inject_failure(bspgemm_comm *comm, int what);
 int            bspgemm_comm_rank(const bspgemm_comm *comm);
 int            bspgemm_comm_size(const bspgemm_comm *comm);
 /* Second half of a stitch whose collective ran elsewhere (bspgemm/dist.py: torch.distributed):

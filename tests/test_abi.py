@@ -98,3 +98,23 @@ def test_one_hip_runtime_per_process():
                                             os.path.join(ROOT, "binary-spgemm_amd", "libbspgemm.so"))
     r = subprocess.run([sys.executable, "-c", bad], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "refused: two HIP runtimes" in r.stdout, r.stdout + r.stderr
+
+
+def test_shipped_library_has_no_ablation_paths():
+    """the shipped .so was one -DBSP_ABLATE away from a silent wrong answer.  The timing-only
+    ablation branches are gone from the kernel sources, the tuning constants are not overridable, and the
+    library says so (bspgemm_build_info)."""
+    import glob
+    info = bspgemm.lib().bspgemm_build_info().decode()
+    assert "BSP_ABLATE=0" in info and "gfx950" in info, info
+    src = glob.glob(os.path.join(ROOT, "binary-spgemm_amd", "csrc", "*"))
+    assert len(src) > 10
+    for path in src:
+        text = open(path).read()
+        for word in ("BSP_ABLATE", "BSP_DENSE_ABLATE", "BSP_DENSE_NOEMIT", "BSP_COMPACT_NOSLOW"):
+            if os.path.basename(path) == "api.hip" and word == "BSP_ABLATE":
+                continue                                   # the text of bspgemm_build_info
+            assert word not in text, "%s still mentions %s" % (path, word)
+        assert "#ifndef BSP_" not in text, "%s has a -D overridable kernel switch" % path
+    mk = open(os.path.join(ROOT, "binary-spgemm_amd", "Makefile")).read()
+    assert "ABLATE" not in mk and "XDEF" not in mk

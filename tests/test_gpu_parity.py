@@ -502,6 +502,14 @@ def test_baseline_cfg4_rmat_scale24_shards(ctx):
             erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, r0 + s0, r0 + s0 + 32)
             assert np.array_equal(crp[s0:s0 + 33] - crp[s0], erp)
             assert np.array_equal(cols[int(crp[s0]): int(crp[s0 + 32])].cpu().numpy(), eci)
+        if p == 3:
+            # one whole shard compared completely (cfg4 was only sampled): row_ptr and every column
+            # index of these rows against the oracle's OpenMP restatement of SpGEMM_omp run on this row range
+            _, cci = C.download()
+            erp, eci = O.spgemm_omp(rp, ci, rp, ci, n, 4096, 0, row0=r0, rows=r1 - r0)
+            assert np.array_equal(crp, erp)
+            assert np.array_equal(cci, eci)
+            del cci, erp, eci
         total_nnz += C.nnz
         total_F += st["products"]
         C.free()
@@ -512,7 +520,8 @@ def test_baseline_cfg4_rmat_scale24_shards(ctx):
 
 def test_baseline_cfg5_powerlaw_full_size(ctx):
     """BASELINE config 5 at full size: power-law n = 2^20, mean degree 64 -- all capacity classes and
-    ~170 K dense-window rows; well-formed, product count exact, hub and tail rows sampled exactly."""
+    ~170 K dense-window rows; well-formed, product count exact, hub and tail rows sampled exactly, then the
+    whole product compared with the oracle."""
     import torch
     from bspgemm import dist as bdist
     rp, ci, n = bspgemm.gen_powerlaw(1 << 20, 64, seed=1)
@@ -527,7 +536,14 @@ def test_baseline_cfg5_powerlaw_full_size(ctx):
     hub = int(np.argmax(deg))
     starts = [0, max(hub - 8, 0), n // 3, n - 64]
     _sampled_rows_exact(rp, ci, n, crp, cols, starts, block=16)
+    del cols
+    # everything (64 sampled rows were thin for the config whose point is the heavy-row kernels):
+    # row_ptr and all 1.87 G column indices against the oracle's OpenMP run
+    _, cci = C.download()
     C.free()
+    erp, eci = O.spgemm_omp(rp, ci, rp, ci, n, 4096, 0)
+    assert np.array_equal(crp, erp)
+    assert np.array_equal(cci, eci)
 
 
 def test_more_than_int32_output_nonzeros(ctx):

@@ -7,7 +7,7 @@ import sys
 
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Iinclude", "-I../include",
-       "-DBSP_ABLATE=0", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
+       "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], {}
 for line in err.splitlines():
