@@ -2,10 +2,15 @@
 """bench.py -- headline benchmark: boolean SpGEMM C = A*A, output nonzeros per second.
 
 A "step" is one full pass of the hot path over one synthetic matrix that is already resident
-in HBM: bspgemm_multiply (row work -> classes -> exact row sizes -> scan = C.row_ptr -> every row
-emitted at its final place) on this rank's A-row shard, plus, for N > 1, the all-gather that
-stitches C.row_ptr (the job of SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  The timed
-region mirrors the reference's (:320-324): inputs resident, result allocation included, no file I/O.
+in HBM: bspgemm_multiply on this rank's A-row shard, plus, for N > 1, the all-gather that stitches
+C.row_ptr (the job of SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  The library's DEFAULT
+flow is timed (`roofline.flow` names it): products per row -> capacity classes -> rows accumulated and
+placed by their product count (an upper bound) -> counts scanned into C.row_ptr -> rows squeezed into
+C.col_idx (k_compact).  The north star's symbolic -> scan -> numeric order is the "exact" flow
+(BSPGEMM_FLOW=exact: 7.9 ms per step on this workload against 7.0) and the single-pass row-order
+"fused" flow is BSPGEMM_FLOW=fused (DESIGN.md section 2 has all three side by side).  The timed region
+mirrors the reference's (:320-324): inputs resident, result allocation included, no file I/O --
+"allocation" here is a hit in the context's cache of freed results (config.allocation).
 
 Workloads (BASELINE.json configs, R-MAT edge factor 16, (a,b,c,d) = (0.30,0.25,0.25,0.20), seed 1,
 SURVEY.md 8d/9.2):
@@ -71,10 +76,37 @@ def spawn_ranks(args):
         env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) // args.gpus))))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # poll ALL children: a rank that dies leaves the others in an RCCL init or barrier for ever, and a
+    # launcher blocked on rank 0's pipe would hang with them until the driver's limit
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("BSPGEMM_BENCH_DEADLINE_S", "3000"))
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = "rank %s exited with %s" % (bad[0], codes[bad[0]]) if bad else "deadline passed"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(10)
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
+    if failed:
+        print("[bench] %s: the other ranks were stopped" % failed, file=sys.stderr, flush=True)
+        return 1
     return max(abs(c) for c in codes)
 
 
@@ -135,7 +167,7 @@ def cpu_baseline(rp, ci, n, budget_s=6.0):
     gomp = ctypes.CDLL("libgomp.so.1", mode=ctypes.RTLD_GLOBAL)     # the runtime oracle/_ref links: one per process
     host_cpus = os.cpu_count() or 1
     usable = len(os.sched_getaffinity(0))
-    C = min(16, usable)                     # one GPU's CPU share on the box
+    C = min(int(os.environ.get("BSPGEMM_BENCH_CPU_CORES", "16")), usable)   # one GPU's CPU share on the box
 
     def run(threads, row0, rows):
         unit = threads * 8                  # decomposition stays divisible (reference README.md:14)
@@ -177,11 +209,83 @@ def cpu_baseline(rp, ci, n, budget_s=6.0):
     if not sweep:
         return None
     best = max(sweep, key=lambda r: r["GNZ/s"])
-    return {"value": best["GNZ/s"], "unit": "GNZ/s", "cores": best["omp_get_max_threads"], "kind": kind,
-            "sample": "rows [%d,%d) of the same matrix (%d output nonzeros), SpGEMM_omp, omp_set_num_threads(%d), "
-                      "tBlock=%d, %.2f s" % (best["row0"], best["row0"] + best["rows"], best["nnz"], best["threads"],
-                                             best["tBlock"], best["seconds"]),
-            "thread_sweep": sweep, "host_cpus": host_cpus, "usable_cpus": usable}
+    out = {"value": best["GNZ/s"], "unit": "GNZ/s", "cores": best["omp_get_max_threads"], "kind": kind,
+           "layout": "OpenMP only (SpGEMM_omp through ctypes), %d threads" % best["threads"],
+           "sample": "rows [%d,%d) of the same matrix (%d output nonzeros), SpGEMM_omp, omp_set_num_threads(%d), "
+                     "tBlock=%d, %.2f s" % (best["row0"], best["row0"] + best["rows"], best["nnz"], best["threads"],
+                                            best["tBlock"], best["seconds"]),
+           "thread_sweep": sweep, "host_cpus": host_cpus, "usable_cpus": usable,
+           "cpu_share": "%d cores = one GPU's share of this host; BSPGEMM_BENCH_CPU_CORES raises it" % C}
+    # ... and the reference's MPI + OpenMP program itself, the layout its report found fastest on a node
+    # (pure MPI, SURVEY.md 6 Fig. 8) included: the best of both is the baseline
+    try:
+        mpi = cpu_baseline_mpirun(C) if kind == "reference" else None
+    except Exception as e:
+        mpi = {"error": repr(e)}
+    out["mpirun"] = mpi
+    if mpi and mpi.get("best") and mpi["best"]["GNZ/s"] > out["value"]:
+        b = mpi["best"]
+        out.update({"value": b["GNZ/s"], "cores": b["cores"],
+                    "layout": "mpirun -n %d x %d OpenMP threads (SpGEMM_mpi_omp binary)" % (b["P"], b["T"]),
+                    "sample": "%s; A*A, %d output nonzeros, median of 3 runs %.3f s (tBlock=%d)"
+                              % (mpi["matrix"], b["Cnnz"], b["median_s"], b["tBlock"])})
+    return out
+
+
+def cpu_baseline_mpirun(budget_cores):
+    """The reference BINARY as its README runs it -- `mpirun -n P SpGEMM_mpi_omp file tBlock T times`
+    (final/SpGEMM_mpi_omp.c:294-366, README.md:12-21) -- built untouched into oracle/_ref, on an R-MAT scale-20
+    file (the bench matrix's generator, a quarter of its rows: the reference's int32 counters and its loader,
+    which every rank runs on the whole file, bound the size) written by bspgemm_write_mtx.  Layouts P x T with
+    P * T = the CPU share of one GPU; median of 3 runs each, from the program's own CSV line."""
+    import shutil
+    import bspgemm
+    exe = os.path.join(ROOT, "oracle", "_ref", "SpGEMM_mpi_omp")
+    mpirun = shutil.which("mpirun") or "/opt/conda/bin/mpirun"
+    if not (os.path.exists(exe) and os.path.exists(mpirun)):
+        return None
+    scale = 20
+    n = 1 << scale
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "bspgemm_bench_rmat%d.mtx" % scale)
+    t0 = time.perf_counter()
+    rp, ci, _ = bspgemm.gen_rmat(scale, 16, RMAT_MILD, seed=1)
+    bspgemm.write_mtx(path, rp, ci, n)
+    t_write = time.perf_counter() - t0
+    layouts = [(p, budget_cores // p) for p in (1, 4, 16, budget_cores) if p <= budget_cores and budget_cores % p == 0]
+    layouts = sorted(set(layouts))
+    runs = []
+    for P, T in layouts:
+        tblock = n // (P * T * 8)                      # 8 slices per thread (SURVEY.md 9.4), divisible (README.md:14-17)
+        if tblock < 1:
+            continue
+        env = dict(os.environ, OMP_NUM_THREADS=str(T), PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
+        cmd = [mpirun, "-n", str(P), exe, path, str(tblock), str(T), "3"]
+        t = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        except subprocess.TimeoutExpired:
+            runs.append({"P": P, "T": T, "tBlock": tblock, "error": "timeout"})
+            continue
+        wall = time.perf_counter() - t
+        line = [x for x in r.stdout.strip().splitlines() if x.count(",") == 10]
+        if r.returncode != 0 or not line:
+            runs.append({"P": P, "T": T, "tBlock": tblock, "error": (r.stderr or r.stdout)[-200:]})
+            continue
+        f = line[-1].split(",")
+        cnnz, median, fastest = int(f[7]), float(f[9]), float(f[10])
+        runs.append({"P": P, "T": T, "cores": P * T, "tBlock": tblock, "Cnnz": cnnz, "median_s": median, "fastest_s": fastest,
+                     "GNZ/s": round(cnnz / median / 1e9, 5), "wall_s_with_loading": round(wall, 1)})
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    ok = [r for r in runs if "GNZ/s" in r]
+    if not ok:
+        return {"runs": runs}
+    best = max(ok, key=lambda r: r["GNZ/s"])
+    return {"best": best, "runs": runs, "matrix": "R-MAT scale %d (same generator and parameters), %d entries, file written in %.1f s"
+                                                 % (scale, int(rp[-1]), t_write),
+            "command": "mpirun -n P oracle/_ref/SpGEMM_mpi_omp <file> tBlock T 3"}
 
 
 def pmc_profile(wname, world):
@@ -411,7 +515,10 @@ def main():
         "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not shared_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
         "config": {"workload": wname, "n": int(n), "nnz_a": int(rp[-1]), "products": products_total,
                    "nnz_c": nnz_total, "parallelism": "row-shards x%d cut at equal work, B replicated" % world,
-                   "shard_rows": [int(b) for b in bounds.tolist()], "priming_steps": priming},
+                   "shard_rows": [int(b) for b in bounds.tolist()], "priming_steps": priming,
+                   "flow": os.environ.get("BSPGEMM_FLOW", "auto"),
+                   "allocation": "cached: C.row_ptr/C.col_idx come from the context's cache of freed results "
+                                 "(two results rotate), workspaces persist; a cold first step allocates (hipMalloc)"},
         "roofline": roofline,
         "whole_job": {"bytes_alg": bytes_total, "bytes_read_alg": read_total,
                       "alg_GBps": round(bytes_total / (ms_per_step * 1e-3) / 1e9, 1),
@@ -428,7 +535,39 @@ def main():
                       "rank0_rows_per_bin": [int(x) for x in st["rows_per_bin"]],
                       "bin_cap": [int(x) for x in st["bin_cap"]]},
     }
+    if use_dist:
+        # what the collective layer itself saw: the first 8-GPU run shows "RCCL saw N ranks" from its own output
+        seen = torch.ones(1, dtype=torch.int64, device=torch.device("cpu") if shared_gpu else dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen": int(seen.item()),
+                       "stitch": "all_gather_into_tensor of int32 row lengths (bspgemm/dist.py) + bspgemm_lengths_to_row_ptr"}
     last.free()
+    if rank == 0 and world == 1 and nnz_total <= 2**31 - 1 and os.environ.get("BSPGEMM_BENCH_NO_DROPIN") != "1":
+        # The call the reference's driver makes (final/SpGEMM_mpi_omp.c:322-327): host int32 arrays in, a malloc'ed
+        # Ccol out, PCIe both ways.  Never the headline: reported beside it.
+        try:
+            import ctypes
+            libc = ctypes.CDLL(None)
+            libc.free.argtypes = [ctypes.c_void_p]
+            L = bspgemm.lib()
+            rp32, ci32 = bspgemm._i32(rp), bspgemm._i32(ci)
+            crow = np.zeros(n + 1, dtype=np.int32)
+            times = []
+            for _ in range(3):
+                cc = ctypes.POINTER(ctypes.c_int)()
+                t = time.perf_counter()
+                rc = L.SpGEMM_hip(ci32, ctypes.c_void_p(rp32.ctypes.data), n, ci32, rp32, n, ctypes.byref(cc), crow, 0)
+                times.append(time.perf_counter() - t)
+                libc.free(ctypes.cast(cc, ctypes.c_void_p))
+                if rc != 0:
+                    raise RuntimeError("SpGEMM_hip returned %d" % rc)
+            best = min(times[1:])
+            out["dropin_e2e"] = {"ms": round(best * 1e3, 1), "GNZ/s": round(int(crow[-1]) / best / 1e9, 3), "nnz_c": int(crow[-1]),
+                                 "what": "SpGEMM_hip(Acol,Arow,An,Acol,Arow,An,&Ccol,Crow,tBlock): upload A (B = A is a view), "
+                                         "multiply, download into the malloc'ed result pinned piecewise under the DMA; "
+                                         "best of 2 after one warm-up call"}
+        except Exception as e:
+            out["dropin_e2e"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(rp, ci, n)

@@ -25,3 +25,25 @@ __attribute__((visibility("hidden"))) void bspgemm_par_prefault(void *p, size_t 
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < n; i++) c[(size_t)i * step] = 0;
 }
+
+/* sum over rows [r0,r1) of min(F_i, cap) with F_i = sum_{j in A_i} |B_j|: how many entries the product of
+ * those rows can have at most (|C_i| <= min(F_i, columns of B)).  One pass over A on all host threads: the
+ * drop-ins size and fault in their malloc'ed result while the GPU is still busy.  Returns -1 if a column of
+ * A is not a row of B (brows). */
+__attribute__((visibility("hidden"))) long long bspgemm_par_output_bound(const int *Acol, const int *Arow, int r0, int r1,
+                                                                        const int *Brow, int brows, long long cap)
+{
+    long long total = 0;
+    int bad = 0;
+#pragma omp parallel for reduction(+ : total) reduction(| : bad) schedule(dynamic, 4096)
+    for (int i = r0; i < r1; i++) {
+        long long f = 0;
+        for (long long k = Arow[i]; k < Arow[i + 1]; k++) {
+            const int j = Acol[k];
+            if (j < 0 || j >= brows) { bad = 1; continue; }
+            f += (long long)Brow[j + 1] - Brow[j];
+        }
+        total += f < cap ? f : cap;
+    }
+    return bad ? -1 : total;
+}
