@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final2")
+SRC = os.path.join(ROOT, "gpurun_out", os.environ.get("BSPGEMM_PROF_DIR", "final2"))
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
@@ -75,6 +75,10 @@ def family_timeline(trace_csv, out_txt, what):
 os.makedirs(DST, exist_ok=True)
 copy("bench_rmat22.json", "bench_rmat22.json")
 copy("bench_rmat22_exact.json", "bench_rmat22_exact_flow.json")
+if one("bench_rmat22_fused.json"):
+    copy("bench_rmat22_fused.json", "bench_rmat22_fused_flow.json")
+if one("dropin.log"):
+    copy("dropin.log", "dropin.log")
 for flow, d in (("", "stats"), ("exact_flow_", "stats_exact")):
     copy(d + "/*/*kernel_stats.csv", flow + "rmat22_kernel_stats.csv")
     if copy(d + "/*/*kernel_trace.csv", flow + "rmat22_kernel_trace.csv"):
