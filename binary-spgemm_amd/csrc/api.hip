@@ -120,6 +120,8 @@ struct bspgemm_context {
     size_t rows_cap = 0;
     long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr, *Fmask = nullptr;
     long long *hpartials = nullptr;     // per scan tile: workspace entries of its heavy rows (scanned)
+    RowRec *hub_rec = nullptr;          // the hub rows' records by decreasing products (kHeavySortMax entries)
+    long long *hub_pre = nullptr;
     int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
     RowRec *rec = nullptr;
     // per-A-nonzero workspace: (start,length) of the B row behind every A nonzero
@@ -282,6 +284,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials);
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
     hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
+    hipFree(ctx->hub_rec); hipFree(ctx->hub_pre);
     hipFree(ctx->tiles); hipFree(ctx->chain); hipFree(ctx->marks8); hipFree(ctx->tile_count); hipFree(ctx->tile_bound);
     hipFree(ctx->pack_totals); hipFree(ctx->tickets);
     if (ctx->h) hipHostFree(ctx->h);
@@ -420,6 +423,10 @@ static bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
+    if (!ctx->hub_rec) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_rec), kHeavySortMax * sizeof(RowRec)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_pre), kHeavySortMax * sizeof(long long)));
+    }
     ctx->rows_cap = cap;
     return BSPGEMM_OK;
 }
@@ -571,6 +578,15 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
 // classes by capacity
 static inline int class_at(int pos) { return pos == 1 ? kDenseBin : (pos == 2 ? kMidBin : pos - 2); }
 
+// the hub rows (class kDenseBin) of a multiply, largest first when there are few enough to rank
+static void hub_order(bspgemm_context *ctx, int b, int n, const RowRec *&rec, const long long *&recpre, hipStream_t sx)
+{
+    if (b != kDenseBin || n < 2 || n > kHeavySortMax) return;
+    launch_order_heavy(rec, recpre, n, ctx->hub_rec, ctx->hub_pre, sx);
+    rec = ctx->hub_rec;
+    recpre = ctx->hub_pre;
+}
+
 // closes the multiply's stat slot (its events have all completed: the caller has synchronised)
 static void close_slot(bspgemm_context *ctx, int R, const HostScalars *h, long long products, long long nnz_c,
                        const int (*cls_n)[kNumBins], int mid_cap)
@@ -702,8 +718,10 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
                 launch_wave_count(b, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols, ctx->ab, rec, n, row_begin,
                                   ctx->cnt, sx);
             } else {
+                const long long *hpre = ctx->recpre + bin_start[b];
+                hub_order(ctx, b, n, rec, hpre, sx);
                 launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
@@ -854,9 +872,11 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
             hipStream_t sx = heavy_lane[k];
             HIPCHK_B(hipStreamWaitEvent(sx, ctx->ev_tile[0][0], 0));
             const RowRec *rec = ctx->rec + bin_start[b];
+            const long long *hpre = ctx->recpre + bin_start[b];
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
+            hub_order(ctx, b, n, rec, hpre, sx);
             launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
-            HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, ctx->recpre + bin_start[b], n,
+            HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
                                        row_begin, ctx->tmp, ctx->cnt, sx));
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
             HIPCHK_B(hipEventRecord(ctx->ev_tile[0][1 + k], sx));
@@ -1005,6 +1025,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
             HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
+            if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
                                  ctx->tmp, ctx->cnt, sx);

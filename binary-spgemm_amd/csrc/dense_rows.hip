@@ -278,6 +278,29 @@ static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, c
     return hipGetLastError();
 }
 
+// Hub rows in order of decreasing products (longest processing time first): one workgroup per row, one per
+// CU, dispatched in list order -- in row order the largest row (it alone is most of the class's critical
+// path: 2 M products on one CU) may start last.  n <= kHeavySortMax: ranks by counting, each thread its own.
+__global__ __launch_bounds__(256) void k_order_heavy(const RowRec *__restrict__ rec, const long long *__restrict__ recpre,
+                                                     int n, RowRec *__restrict__ rec_out, long long *__restrict__ pre_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RowRec me = rec[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const int f = rec[j].f;
+        rank += (f > me.f || (f == me.f && j < i)) ? 1 : 0;
+    }
+    rec_out[rank] = me;
+    pre_out[rank] = recpre[i];
+}
+void launch_order_heavy(const RowRec *rec, const long long *recpre, int n, RowRec *rec_out, long long *pre_out, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_order_heavy, dim3((n + 255) / 256), dim3(256), 0, s, rec, recpre, n, rec_out, pre_out);
+}
+
 hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s)

@@ -128,6 +128,10 @@ hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 
+// the heavy rows' records in order of decreasing products (n <= kHeavySortMax), into rec_out / pre_out
+constexpr int kHeavySortMax = 8192;
+void launch_order_heavy(const RowRec *rec, const long long *recpre, int n, RowRec *rec_out, long long *pre_out, hipStream_t s);
+
 // masked variant: C = F .* (A*B); every non-empty row goes through the window kernel, which
 // keeps only the product bits that F's row (absolute row id, F.row_ptr/F.col_idx) admits
 hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
