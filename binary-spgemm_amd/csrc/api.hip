@@ -89,6 +89,7 @@ struct HostScalars {
     long long heavy_total;              // entries the heavy rows may need in the workspace
     long long pack_totals[2];           // fused flow: number of tiles, sum of min(F_i, cols)
     unsigned chain_err;                 // fused flow: a look-back wait ran out
+    PrepScalars prep;                   // upper-bound flow: the prepass results, fetched in one copy
 };
 
 struct bspgemm_context {
@@ -138,6 +139,7 @@ struct bspgemm_context {
     int *tile_count = nullptr;
     long long *tile_bound = nullptr;
     long long *pack_totals = nullptr;   // 2
+    PrepScalars *d_prep = nullptr;      // device side of HostScalars::prep
     unsigned *tickets = nullptr;        // 8 counters 32 words apart, then the error word
     HostScalars *h = nullptr;          // pinned
     // freed result buffers, reused by the next multiply (results are allocated per call like the
@@ -251,6 +253,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_prep), sizeof(PrepScalars)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) HIPCHK(hipEventCreate(&e));
@@ -288,6 +291,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->tiles); hipFree(ctx->chain); hipFree(ctx->marks8); hipFree(ctx->tile_count); hipFree(ctx->tile_bound);
     hipFree(ctx->pack_totals); hipFree(ctx->tickets);
     if (ctx->h) hipHostFree(ctx->h);
+    hipFree(ctx->d_prep);
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) if (e) hipEventDestroy(e);
         for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) if (e) hipEventDestroy(e);
@@ -980,22 +984,21 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     // rows are classified by their products and placed by min(products, B.cols) -- or, masked, both by
     // the mask row's length (|C_i| <= |F_i|); the true product count is summed separately
     const long long *size_by = ctx->F;
-    launch_sum_i64(ctx->F, R, ctx->partials, s);
-    HIPCHK_B(hipMemcpyAsync(&h->products, ctx->partials + (R > 0 ? (R + 2047) / 2048 : 0), sizeof(long long),
-                            hipMemcpyDeviceToHost, s));
     if (Fm) {
         launch_mask_lengths(ctx->F, Fm->d_row_ptr, row_begin, R, ctx->Fmask, s);
         size_by = ctx->Fmask;
     }
     launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols),
-                        B->cols > 0 ? B->cols : 1, s);
-    HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
-    HIPCHK_B(hipMemcpyAsync(h->bin_count, ctx->bin_count, kNumBins * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK_B(hipMemcpyAsync(&h->a_lo, A->d_row_ptr + row_begin, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK_B(hipMemcpyAsync(&h->a_hi, A->d_row_ptr + row_end, sizeof(int), hipMemcpyDeviceToHost, s));
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, ctx->hpartials, mid_cap_for_cols(B->cols),
+                        B->cols > 0 ? B->cols : 1, s, ctx->d_prep, Fm ? ctx->F : nullptr);
+    HIPCHK_B(hipMemcpyAsync(&h->prep, ctx->d_prep, sizeof(PrepScalars), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipEventRecord(slot.ev[1], s));
     HIPCHK_B(hipStreamSynchronize(s));
+    h->totalF = h->prep.totalF;
+    h->products = h->prep.products;
+    h->a_lo = h->prep.a_lo;
+    h->a_hi = h->prep.a_hi;
+    memcpy(h->bin_count, h->prep.bin_count, sizeof h->bin_count);
     const long long total = R > 0 ? h->totalF : 0;         // sum of min(products, cols) (masked: of mask-row lengths): bounds nnz(C)
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
     if (bspgemm_status st = ensure_tmp(ctx, (size_t)total + 1)) return bail(st);

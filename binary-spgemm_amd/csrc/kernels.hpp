@@ -98,10 +98,20 @@ void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const
 // heavy_cols > 0: the heavy rows (class kDenseBin) get their own workspace offsets in recpre --
 // exclusive prefix of min(F_i, heavy_cols) over the heavy rows -- and hpartials[ceil(n/2048)]
 // holds that workspace's total size; one-wave rows are then placed by the symbolic counts.
+// `scal` (device, may be NULL): everything the host reads back after the prepass in one struct --
+// without a heavy-row workspace (heavy_cols <= 0) also the product count, summed from `true_F` when
+// the rows are sized by something else than their products (masked multiply), else from F.
+struct PrepScalars {
+    long long totalF;
+    long long heavy_total;
+    long long products;
+    int a_lo, a_hi;
+    int bin_count[kNumBins];
+};
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
                          long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
-                         hipStream_t s);
+                         hipStream_t s, PrepScalars *scal = nullptr, const long long *true_F = nullptr);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
@@ -145,8 +155,6 @@ void launch_wave_masked(int bin, const int2 *ab, const int *Bcol, int cols, cons
                         int *tmp, int *cnt, hipStream_t s);
 // mlen[i] = |F's row i| when row i has products, else 0: what the masked product bins and offsets by
 void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int n, long long *mlen, hipStream_t s);
-// partials[ceil(n/2048)] = sum of F[0..n)
-void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s);
 
 // rows [row_lo,row_hi): tmp[Fprefix[r] .. +cnt[r])  ->  col_idx[row_ptr[r] ..).  The output range
 // is read from row_ptr on the device; `max_out` (an upper bound of its length, e.g. the rows'

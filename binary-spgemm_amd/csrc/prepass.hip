@@ -324,19 +324,22 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
                                                             long long *__restrict__ partials,
                                                             int *__restrict__ bin_tiles,
                                                             int heavy_cols, long long *__restrict__ hpartials,
-                                                            int mid_cap, int bound_cols)
+                                                            int mid_cap, int bound_cols,
+                                                            const long long *__restrict__ true_in,
+                                                            long long *__restrict__ ppartials)
 {
-    __shared__ long long lds[4], ldh[4];
+    __shared__ long long lds[4], ldh[4], ldp[4];
     __shared__ int lcount[kNumBins];
     if (BIN && threadIdx.x < kNumBins) lcount[threadIdx.x] = 0;
     if (BIN) __syncthreads();
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    long long v = 0, hv = 0;
+    long long v = 0, hv = 0, pv = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++)
         if (base + k < n) {
             const long long x = (long long)in[base + k];
             v += (BIN && bound_cols > 0 && x > bound_cols) ? (long long)bound_cols : x;   // what is PLACED: |C_i| <= min(F_i, cols)
+            if (BIN && ppartials) pv += true_in ? true_in[base + k] : x;                 // the products themselves
             if (BIN) {
                 const int b = bin_of(x, mid_cap);
                 atomicAdd(&lcount[b], 1);
@@ -350,10 +353,16 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
         hv = wave_incl_scan64(hv);
         if (lane == 63) ldh[w] = hv;
     }
+    if (BIN && ppartials) {                                    // uniform
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) pv += __shfl_xor(pv, d, 64);
+        if (lane == 0) ldp[w] = pv;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         partials[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
         if (BIN && heavy_cols > 0) hpartials[blockIdx.x] = ldh[0] + ldh[1] + ldh[2] + ldh[3];
+        if (BIN && ppartials) ppartials[blockIdx.x] = ldp[0] + ldp[1] + ldp[2] + ldp[3];
     }
     if (BIN && threadIdx.x < kNumBins) bin_tiles[blockIdx.x * kNumBins + threadIdx.x] = lcount[threadIdx.x];
 }
@@ -387,23 +396,45 @@ __device__ __forceinline__ void scan_column(V *vals, int m, int stride, long lon
 }
 
 // block 0 scans the tile sums; blocks 1..kNumBins (BIN only) scan one capacity class's per-tile
-// counts; block kNumBins+1 (heavy-row workspace in use) scans the heavy-row bounds
+// counts; block kNumBins+1 scans the heavy-row bounds (heavy-row workspace in use) or, `sum_only`,
+// just adds up hpartials[] (there the per-tile product counts).  `scal` (may be NULL) collects what
+// the host reads back after the prepass, so that it is one copy instead of five.
 __global__ __launch_bounds__(1024) void k_scan_partials(long long *__restrict__ partials, int m,
                                                         int *__restrict__ bin_tiles,
                                                         int *__restrict__ bin_count,
-                                                        long long *__restrict__ hpartials)
+                                                        long long *__restrict__ hpartials, int sum_only,
+                                                        PrepScalars *__restrict__ scal)
 {
     __shared__ long long wsum[16];
     __shared__ long long carry_s;
     if (blockIdx.x == 0) {
         scan_column<long long>(partials, m, 1, wsum, &carry_s);
     } else if (blockIdx.x == kNumBins + 1) {
-        scan_column<long long>(hpartials, m, 1, wsum, &carry_s);
+        if (sum_only) {
+            long long v = 0;
+            for (int i = threadIdx.x; i < m; i += 1024) v += hpartials[i];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+            if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long t = 0;
+                for (int k = 0; k < 16; k++) t += wsum[k];
+                scal->products = t;
+            }
+        } else {
+            scan_column<long long>(hpartials, m, 1, wsum, &carry_s);
+            if (scal && threadIdx.x == 0) scal->heavy_total = hpartials[m];
+        }
     } else {
         const int b = blockIdx.x - 1;
         scan_column<int>(bin_tiles + b, m, kNumBins, wsum, &carry_s);
         __syncthreads();
-        if (threadIdx.x == 0) bin_count[b] = bin_tiles[(size_t)m * kNumBins + b];
+        if (threadIdx.x == 0) {
+            const int c = bin_tiles[(size_t)m * kNumBins + b];
+            bin_count[b] = c;
+            if (scal) scal->bin_count[b] = c;
+        }
     }
 }
 
@@ -423,7 +454,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              const long long *carry_in,
                                                              int heavy_cols,
                                                              const long long *__restrict__ hpartials,
-                                                             int mid_cap, int bound_cols)
+                                                             int mid_cap, int bound_cols,
+                                                             PrepScalars *__restrict__ scal)
 {
     __shared__ long long wsum[4], hsum[4];
     __shared__ int lcount[kNumBins];
@@ -490,35 +522,39 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
         }
         off += pl[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = base0 + partials[gridDim.x];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const long long total = base0 + partials[gridDim.x];
+        out[n] = total;
+        if (BIN && scal) {
+            scal->totalF = total;
+            scal->a_lo = Arow[row_begin];
+            scal->a_hi = Arow[row_begin + n];
+        }
+    }
 }
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
                          long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
-                         hipStream_t s)
+                         hipStream_t s, PrepScalars *scal, const long long *true_F)
 {
     if (n <= 0) {
         hipMemsetAsync(prefix, 0, sizeof(long long), s);
         hipMemsetAsync(bin_count, 0, kNumBins * sizeof(int), s);
         if (heavy_cols > 0) hipMemsetAsync(hpartials, 0, sizeof(long long), s);
+        if (scal) hipMemsetAsync(scal, 0, sizeof(PrepScalars), s);
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
+    // without a heavy-row workspace hpartials[] is free: it carries the per-tile product counts
+    const bool count_products = scal && heavy_cols <= 0;
     hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles,
-                       heavy_cols, hpartials, mid_cap, bound_cols);
-    hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0, s, partials,
-                       tiles, bin_tiles, bin_count, hpartials);
+                       heavy_cols, hpartials, mid_cap, bound_cols, true_F, count_products ? hpartials : nullptr);
+    hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 || count_products ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0,
+                       s, partials, tiles, bin_tiles, bin_count, hpartials, count_products ? 1 : 0, scal);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
-                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials, mid_cap, bound_cols);
-}
-
-void launch_sum_i64(const long long *F, int n, long long *partials, hipStream_t s)
-{
-    if (n <= 0) { hipMemsetAsync(partials, 0, sizeof(long long), s); return; }
-    const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<long long, false>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, nullptr, 0, nullptr, 0, 0);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
+                       prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials,
+                       mid_cap, bound_cols, scal);
 }
 
 // prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
@@ -531,10 +567,10 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr, 0, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
