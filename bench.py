@@ -442,8 +442,8 @@ def main():
         # nonzero + 12 B/A-nonzero + 12 B/row) over the HIP-event time from the first instance's start
         # to the last one's end on the multiply's stream (bspgemm_stats.ms_numeric).  Per-instance
         # event brackets are listed next to it; they overlap pairwise, so their sum exceeds the
-        # family's time.  `symbolic` prices the count kernels (k_wave_count family) the same way with
-        # what they move: 4 B/product + 8 B/A-nonzero + 4 B/row.
+        # family's time.  `symbolic` prices the count kernels (the COUNT instances of the same source) the
+        # same way with what they move: 4 B/product + 8 B/A-nonzero + 4 B/row.
         crp, _ = last.download(col_idx=False)
         F_row = np.diff(prefix)[r0:r1]
         a_row = np.diff(rp.astype(np.int64))[r0:r1]
@@ -471,7 +471,7 @@ def main():
                                   "GBps_while_sharing_the_gpu": round(by / (ms_b * 1e-3) / 1e9, 1) if ms_b > 0 else 0.0})
         traffic, traffic_src = None, None
         if prof:
-            fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels)]
+            fam = [v for k, v in prof.get("kernels", {}).items() if k.startswith("bsp::k_wave_rows<%d," % levels) and not k.rstrip().endswith("true>")]
             if len(fam) == len(instances):
                 # FETCH_SIZE under-counts wide coalesced reads 2x on gfx950 (MI355X_MICROARCH.md, HBM): the
                 # gathers of this kernel are 4-byte accesses, so the raw figure is quoted, uncorrected
@@ -492,7 +492,7 @@ def main():
                     "launch_rows": int(wave.sum()), "launch_products": int(F_row[wave].sum()),
                     "steps_averaged": len(hist), "instances": instances, "flow": flow}
         if flow == "exact":
-            roofline["symbolic"] = {"kernel": "k_wave_count<*> (symbolic pass: exact row sizes, hash set in LDS)",
+            roofline["symbolic"] = {"kernel": "k_wave_rows<LEVELS=%d,*,COUNT> (symbolic pass: exact row sizes, the rank bitmap without its emit half)" % levels,
                                     "bytes_per_launch": sym_bytes, "ms_per_launch": round(ms_cnt, 4),
                                     "achieved": round(sym_bytes / (ms_cnt * 1e-3) / 1e9, 1) if ms_cnt > 0 else None,
                                     "frac": round(sym_bytes / (ms_cnt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms_cnt > 0 else None}

@@ -672,8 +672,10 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     // ---- symbolic 1: per-row products, their prefix, capacity classes ---------------------
     const int scan_tiles = (R + 2047) / 2048;
     const int heavy_cols = B->cols > 0 ? B->cols : 1;
-    if (bspgemm_status st = ensure_deg8(B)) return bail(st);       // (wrapped device arrays: first use)
-    launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, row_begin, row_end, ctx->F, s);
+    // the extents ab[] come from the prepass, as in the other flow: both passes of the one-wave classes read them
+    if (bspgemm_status st = ensure_blk8(B)) return bail(st);       // (wrapped device arrays: first use)
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr, row_begin, row_end,
+                    ctx->F, ctx->ab, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
     HostScalars *h = ctx->h;
@@ -719,12 +721,13 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             const RowRec *rec = ctx->rec + bin_start[b];
             HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
             if (b <= kWaveBins) {
-                launch_wave_count(b, A->d_col_idx, B->d_row_ptr, B->d_col_idx, B->cols, ctx->ab, rec, n, row_begin,
-                                  ctx->cnt, sx);
+                // the numeric kernel without its emit half: |C_i| = F_i as soon as every product is seen to sit alone
+                // in its 32-column slot, the level-0 masks are only built and counted for the other rows
+                launch_wave_rows(b, wave_levels_for_cols(B->cols), ctx->ab, B->d_col_idx, B->cols, rec, nullptr, nullptr, n,
+                                 row_begin, nullptr, ctx->cnt, sx, true);
             } else {
                 const long long *hpre = ctx->recpre + bin_start[b];
                 hub_order(ctx, b, n, rec, hpre, sx);
-                launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
                 HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }

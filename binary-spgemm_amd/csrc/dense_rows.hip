@@ -12,7 +12,8 @@
 // independent loads in flight per thread, whatever the B-row lengths are.
 // When cols > 2^20 the row's products are re-gathered once per window (B is L2/MALL resident
 // for a hub row: its B rows were just read by the previous window).
-// Also holds the compaction kernels that squeeze the upper-bound-placed rows into C.col_idx.
+// Also holds the exact flow's move of the heavy rows (k_place_heavy) and the compaction kernel that squeezes the
+// upper-bound-placed rows into C.col_idx.
 #include "kernels.hpp"
 #include "wave.hpp"
 
@@ -315,6 +316,32 @@ hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
                                     int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s)
 {
     return launch_dense_impl<true, kDenseThreadsBig>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact flow: heavy rows keep the upper-bound placement -- k_dense_rows accumulates AND reads out in the
+// symbolic phase (its window bitmap is the expensive part; counting alone would cost almost the same), into
+// a workspace sized by sum(min(F_i, cols)) over the heavy rows only, and this kernel moves each
+// heavy row to its final place once C.row_ptr exists.  One workgroup per heavy row.
+__global__ __launch_bounds__(256) void k_place_heavy(const int *__restrict__ tmp, const RowRec *__restrict__ rec,
+                                                     const long long *__restrict__ recpre,
+                                                     const long long *__restrict__ row_ptr, int row_begin,
+                                                     int *__restrict__ col_idx)
+{
+    const RowRec q = rec[blockIdx.x];
+    const int i = q.row - row_begin;
+    const long long d0 = row_ptr[i];
+    const int n = (int)(row_ptr[i + 1] - d0);
+    const int *src = tmp + recpre[blockIdx.x];
+    int *dst = col_idx + d0;
+    for (int t = threadIdx.x; t < n; t += 256) dst[t] = src[t];
+}
+
+void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,
+                        const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s)
+{
+    if (nrows <= 0) return;
+    hipLaunchKernelGGL(k_place_heavy, dim3(nrows), dim3(256), 0, s, tmp, rec, recpre, row_ptr, row_begin, col_idx);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -117,17 +117,13 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
                         const long long *base, hipStream_t s);
 
-// symbolic phase, one wave per row: gathers the row's B-row extents (left in ab[] for the numeric
-// phase), then cnt[row] = |C_row| exactly (hash set in LDS, nothing emitted)
-void launch_wave_count(int bin, const int *Acol, const int *Brow, const int *Bcol, int cols, int2 *ab,
-                       const RowRec *rec, int nrows, int row_begin, int *cnt, hipStream_t s);
-
 // numeric phase, one wave per row (rank-bitmap accumulator).  row_ptr != NULL: row i is written at
 // tmp + row_ptr[i - row_begin] (tmp = C.col_idx, sizes known from the symbolic phase, cnt may be
 // NULL); row_ptr == NULL: at its upper-bound offset tmp + recpre[k], |C_i| to cnt (masked product)
+// count_only: the symbolic twin of the same kernel -- nothing is emitted (tmp, recpre, row_ptr unused), cnt[i] = |C_i|
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
-                      int row_begin, int *tmp, int *cnt, hipStream_t s);
+                      int row_begin, int *tmp, int *cnt, hipStream_t s, bool count_only = false);
 
 // heavy rows: workspace -> final place (one workgroup per heavy row)
 void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,

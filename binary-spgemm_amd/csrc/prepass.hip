@@ -217,9 +217,8 @@ void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const in
 }
 
 // ---------------------------------------------------------------------------------------
-// Products per row WITHOUT the extents: the plain product only needs F_i here (capacity classes,
-// shard cuts); its count kernels gather the B-row extents themselves, hidden behind their hashing
-// (wave_count.hip).  What is gathered per A-nonzero is ONE BYTE from a table that fits an XCD's
+// Products per row WITHOUT the extents: where only F_i is needed (shard cuts, the fused flow's tile
+// packing, the closure's sizing).  What is gathered per A-nonzero is ONE BYTE from a table that fits an XCD's
 // L2 for matrices up to ~4 M rows -- B's row lengths clamped to 255, built once per operand --
 // instead of an 8-byte B.row_ptr pair out of a table four to eight times the L2 (the pair gather
 // is what bounds k_row_work: one 64-byte sector fetched per nonzero).  A clamped entry (a B row

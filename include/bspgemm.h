@@ -113,7 +113,7 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
  *                of F entries and squeezed into C.col_idx once the counts are scanned -- the GPU
  *                form of the reference's append-then-concatenate (final/SpGEMM_mpi_omp.c:38-42,
  *                110-131); holds 2F entries.
- *   EXACT        a symbolic pass sizes every row exactly first (hash-set count kernels), C.row_ptr
+ *   EXACT        a symbolic pass sizes every row exactly first (the accumulate kernels without their emit half), C.row_ptr
  *                is their scan, and the numeric pass emits every row at its final place: nnz(C)
  *                entries, no F-sized workspace.
  *   FUSED        rows are accumulated in ROW ORDER by tiles of consecutive rows in one persistent kernel;
@@ -185,7 +185,7 @@ typedef struct bspgemm_stats {
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* = ms_prepass + ms_count: everything that sizes C.row_ptr     */
     float   ms_prepass;      /*   row work (products per row) + scan + capacity classes      */
-    float   ms_count;        /*   exact row sizes (hash-set count kernels, heavy rows) + scan */
+    float   ms_count;        /*   exact row sizes (count pass of the one-wave classes, heavy rows) + scan */
     float   ms_numeric;      /* accumulate + emit kernels, rows written at their final place */
     float   ms_stitch;       /* what is left exposed after them (heavy-row move; masked
                                 product: count scan + compaction)                            */
