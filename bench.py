@@ -7,7 +7,7 @@ C.row_ptr (the job of SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  Th
 flow is timed (`roofline.flow` names it): products per row -> capacity classes -> rows accumulated and
 placed by their product count (an upper bound) -> counts scanned into C.row_ptr -> rows squeezed into
 C.col_idx (k_compact).  The north star's symbolic -> scan -> numeric order is the "exact" flow
-(BSPGEMM_FLOW=exact: 7.9 ms per step on this workload against 7.0) and the single-pass row-order
+(BSPGEMM_FLOW=exact: 7.3 ms per step on this workload against 7.0) and the single-pass row-order
 "fused" flow is BSPGEMM_FLOW=fused (DESIGN.md section 2 has all three side by side).  The timed region
 mirrors the reference's (:320-324): inputs resident, result allocation included, no file I/O --
 "allocation" here is a hit in the context's cache of freed results (config.allocation).
