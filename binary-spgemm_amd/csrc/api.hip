@@ -140,6 +140,8 @@ struct bspgemm_context {
     long long *tile_bound = nullptr;
     long long *pack_totals = nullptr;   // 2
     PrepScalars *d_prep = nullptr;      // device side of HostScalars::prep
+    int *chunk_row = nullptr;           // compaction: row of every kCompactGran-th output (left by the count scan)
+    size_t chunk_cap = 0;
     unsigned *tickets = nullptr;        // 8 counters 32 words apart, then the error word
     HostScalars *h = nullptr;          // pinned
     // freed result buffers, reused by the next multiply (results are allocated per call like the
@@ -292,6 +294,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->pack_totals); hipFree(ctx->tickets);
     if (ctx->h) hipHostFree(ctx->h);
     hipFree(ctx->d_prep);
+    hipFree(ctx->chunk_row);
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) if (e) hipEventDestroy(e);
         for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) if (e) hipEventDestroy(e);
@@ -486,6 +489,19 @@ static bspgemm_status ensure_tmp(bspgemm_context *ctx, size_t ints)
     }
     HIPCHK(e);
     ctx->tmp_cap = cap;
+    return BSPGEMM_OK;
+}
+
+static bspgemm_status ensure_chunk_rows(bspgemm_context *ctx, size_t entries)
+{
+    if (entries <= ctx->chunk_cap) return BSPGEMM_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->chunk_row);
+    ctx->chunk_row = nullptr;
+    ctx->chunk_cap = 0;
+    const size_t cap = entries + entries / 16 + 64;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->chunk_row), cap * sizeof(int)));
+    ctx->chunk_cap = cap;
     return BSPGEMM_OK;
 }
 
@@ -1030,6 +1046,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     const long long total = R > 0 ? h->totalF : 0;         // sum of min(products, cols) (masked: of mask-row lengths): bounds nnz(C)
     if (R == 0) memset(h->bin_count, 0, sizeof h->bin_count);
     if (bspgemm_status st = ensure_tmp(ctx, (size_t)total + 1)) return bail(st);
+    if (bspgemm_status st = ensure_chunk_rows(ctx, compact_chunk_rows(total))) return bail(st);
     // C.col_idx: a cached buffer of the upper-bound size is taken now (nothing to wait for); else it
     // is allocated with exactly nnz(C) entries once the counts are scanned
     if (result_cached(ctx, result_bytes_colidx(total))) {
@@ -1079,7 +1096,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             HIPCHK_B(hipStreamWaitEvent(s, ctx->ev_tile[0][l], 0));
         }
         HIPCHK_B(hipEventRecord(slot.ev[3], s));
-        launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, nullptr, s);
+        launch_scan_counts(ctx->cnt, R, C->d_row_ptr, ctx->partials, nullptr, s, ctx->chunk_row);
     } else {
         HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
         HIPCHK_B(hipEventRecord(slot.ev[3], s));
@@ -1092,7 +1109,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
         C->col_cap = want;
     }
     if (R > 0) {
-        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, 0, R, total, C->d_col_idx, s);
+        launch_compact(ctx->tmp, ctx->Fprefix, C->d_row_ptr, 0, R, total, C->d_col_idx, s, ctx->chunk_row);
         HIPCHK_B(hipGetLastError());
     }
     HIPCHK_B(hipEventRecord(slot.ev[4], s));

@@ -348,12 +348,15 @@ void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recp
 // Compaction: every row was written at its upper-bound offset Fprefix[r]; now that the counts
 // are scanned into C.row_ptr the rows are copied to their final place.  Pure streaming copy
 // (4 B read + 4 B written per output nonzero), driven by the DESTINATION: a workgroup owns
-// 32768 consecutive output nonzeros (128 KiB of C.col_idx), finds the rows that cover them by a
-// binary search in C.row_ptr, keeps their (row_ptr, shift) pairs in LDS 256 rows at a time and
+// 8192 consecutive output nonzeros (32 KiB of C.col_idx), takes the rows that cover them from the
+// table the count scan left (chunk_row: the row of every 4096th output; without the table -- small
+// products -- 32768 outputs or fewer and a binary search in C.row_ptr), keeps their (row_ptr, shift) pairs in LDS 256 rows at a time and
 // copies 16 B per lane whenever four outputs lie in one row -- stores are always 16-B aligned
 // and fully coalesced, loads are the same stream displaced by the row's shift.  Work per
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
-constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup (a small product gets smaller chunks: see launch_compact)
+constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup when its rows are searched (a small product gets smaller chunks: see launch_compact)
+constexpr int kCompactChunkTable = 8192; // ... when the count scan left the row table (chunk_row): a multiple of kCompactGran
+static_assert(kCompactChunkTable % kCompactGran == 0, "chunk starts must be entries of the row table");
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
 constexpr int kCompactInFlight = 4;      // 16-B groups a thread has in flight (8 measured slower)
 constexpr int kCompactSparseRows = 4096; // a chunk spanning more rows than this is searched per output
@@ -364,7 +367,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                                                  const long long *__restrict__ Fprefix,
                                                  const long long *__restrict__ row_ptr,
-                                                 int row_lo, int row_hi, int chunk, int *__restrict__ col_idx)
+                                                 int row_lo, int row_hi, int chunk, int *__restrict__ col_idx,
+                                                 const int *__restrict__ chunk_row)
 {
     __shared__ long long rp[kCompactBatch + 1];
     __shared__ long long sh[kCompactBatch];      // source offset - destination offset of the row
@@ -377,7 +381,11 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
     if (o0 < out_lo) o0 = out_lo;
     if (o1 > out_hi) o1 = out_hi;
     if (o0 >= o1) return;                        // uniform: the grid is sized by an upper bound
-    if (tid == 0) {
+    if (tid == 0 && chunk_row) {
+        // the count scan left the row of every kCompactGran-th output (the chunk is a multiple of that, row_lo == 0)
+        r_first = chunk_row[o0 / kCompactGran];
+        r_last = chunk_row[(o1 + kCompactGran - 1) / kCompactGran];   // row of output o1, or of the last output
+    } else if (tid == 0) {
         // last row r in [row_lo,row_hi) with row_ptr[r] <= o0: non-empty and contains output o0
         int lo = row_lo, hi = row_hi;            // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
         while (hi - lo > 1) {
@@ -464,16 +472,25 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
 }
 
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s)
+                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s, const int *chunk_row)
 {
     if (row_hi <= row_lo || max_out <= 0) return;
-    // chunk: a multiple of 4 outputs (aligned 16-B stores); a small product is cut finer so that it
-    // still spreads over the chip (one 32768-output chunk would be ONE workgroup walking every row)
+    // chunk: a multiple of 4 outputs (aligned 16-B stores).  With the scan's row table a workgroup's set-up is two
+    // loads instead of two binary searches in C.row_ptr, and smaller chunks pay: 8192 outputs (32 KiB) measured best
+    // (stitch phase on the bench matrix 2.35 ms searched at 32768; with the table 2.24 at 32768, 2.18 at 16384,
+    // 2.16 at 8192, 2.30 at 4096; power-law 2.85 -> 2.56: `profiles/r03_ab_compaction.log`).  A small product is
+    // cut finer still so that it spreads over the chip (one large chunk would be ONE workgroup walking every row);
+    // those chunks are not multiples of the table's grain and are searched.
     long long chunk = ((max_out / 2048) + 3) & ~3ll;
     if (chunk < 256) chunk = 256;
-    if (chunk > kCompactChunk) chunk = kCompactChunk;
+    if (chunk >= kCompactChunkTable && chunk_row && row_lo == 0) {
+        chunk = kCompactChunkTable;
+    } else {
+        chunk_row = nullptr;
+        if (chunk > kCompactChunk) chunk = kCompactChunk;
+    }
     const int grid = (int)((max_out + 3 + chunk - 1) / chunk) + 1;
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, row_lo, row_hi, (int)chunk, col_idx);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, tmp, Fprefix, row_ptr, row_lo, row_hi, (int)chunk, col_idx, chunk_row);
 }
 
 }  // namespace bsp

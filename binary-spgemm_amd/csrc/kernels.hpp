@@ -114,8 +114,13 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
                          hipStream_t s, PrepScalars *scal = nullptr, const long long *true_F = nullptr);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
+// `chunk_row` (may be NULL; needs base == NULL): chunk_row[c] = the row that holds output c * kCompactGran, for every
+// such output below the total, and chunk_row[ceil(total / kCompactGran)] = the row of the last output -- the
+// compaction's row look-up, left behind by the scan that knows every row's range anyway
+constexpr int kCompactGran = 4096;
+inline size_t compact_chunk_rows(long long max_out) { return (size_t)((max_out + kCompactGran - 1) / kCompactGran) + 2; }
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
-                        const long long *base, hipStream_t s);
+                        const long long *base, hipStream_t s, int *chunk_row = nullptr);
 
 // numeric phase, one wave per row (rank-bitmap accumulator).  row_ptr != NULL: row i is written at
 // tmp + row_ptr[i - row_begin] (tmp = C.col_idx, sizes known from the symbolic phase, cnt may be
@@ -156,7 +161,7 @@ void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int
 // is read from row_ptr on the device; `max_out` (an upper bound of its length, e.g. the rows'
 // product count) only sizes the grid.
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
-                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s);
+                    int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s, const int *chunk_row = nullptr);
 
 // ---- fused flow: tiles of consecutive rows, one persistent kernel, rows written once -------------
 // a tile = rows [row0, row0 + nrows) of the multiplied range (row0 relative to row_begin)

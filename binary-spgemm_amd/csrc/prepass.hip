@@ -454,7 +454,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              int heavy_cols,
                                                              const long long *__restrict__ hpartials,
                                                              int mid_cap, int bound_cols,
-                                                             PrepScalars *__restrict__ scal)
+                                                             PrepScalars *__restrict__ scal,
+                                                             int *__restrict__ chunk_row)
 {
     __shared__ long long wsum[4], hsum[4];
     __shared__ int lcount[kNumBins];
@@ -498,6 +499,13 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
     for (int k = 0; k < kScanItems; k++) {
         if (base + k < n) {
             out[base + k] = off;
+            if (!BIN && chunk_row && pl[k] > 0) {
+                // the compaction chunks that START inside this row; the row of the last output closes the last chunk
+                for (long long c = (off + kCompactGran - 1) / kCompactGran; c * kCompactGran < off + pl[k]; c++)
+                    chunk_row[c] = base + k;
+                const long long total = base0 + partials[gridDim.x];
+                if (off + pl[k] == total) chunk_row[(total + kCompactGran - 1) / kCompactGran] = base + k;
+            }
             if (BIN) {
                 const int b = bin_of(v[k], mid_cap);
                 if (b == 0) {
@@ -553,13 +561,13 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
                        s, partials, tiles, bin_tiles, bin_count, hpartials, count_products ? 1 : 0, scal);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
                        prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials,
-                       mid_cap, bound_cols, scal);
+                       mid_cap, bound_cols, scal, nullptr);
 }
 
 // prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
 // prefix[0]: a range of rows continues the row_ptr of the rows before it
 void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *partials,
-                        const long long *base, hipStream_t s)
+                        const long long *base, hipStream_t s, int *chunk_row)
 {
     if (n <= 0) {
         if (!base) hipMemsetAsync(prefix, 0, sizeof(long long), s);
@@ -569,7 +577,8 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
     hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr, 0, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0, nullptr);
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0, nullptr,
+                       base ? nullptr : chunk_row);
 }
 
 // ---------------------------------------------------------------------------------------
