@@ -381,31 +381,36 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
     if (o0 < out_lo) o0 = out_lo;
     if (o1 > out_hi) o1 = out_hi;
     if (o0 >= o1) return;                        // uniform: the grid is sized by an upper bound
-    if (tid == 0 && chunk_row) {
-        // the count scan left the row of every kCompactGran-th output (the chunk is a multiple of that, row_lo == 0)
-        r_first = chunk_row[o0 / kCompactGran];
-        r_last = chunk_row[(o1 + kCompactGran - 1) / kCompactGran];   // row of output o1, or of the last output
-    } else if (tid == 0) {
-        // last row r in [row_lo,row_hi) with row_ptr[r] <= o0: non-empty and contains output o0
-        int lo = row_lo, hi = row_hi;            // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (row_ptr[mid] <= o0) lo = mid; else hi = mid;
+    int rf, rl;                                  // first / last row with outputs in the chunk (rl may be one row further)
+    if (chunk_row) {
+        // the count scan left the row of every kCompactGran-th output (the chunk is a multiple of that, row_lo == 0):
+        // two loads at uniform addresses, no search, no barrier
+        rf = chunk_row[o0 / kCompactGran];
+        rl = chunk_row[(o1 + kCompactGran - 1) / kCompactGran];       // row of output o1, or of the last output
+    } else {
+        if (tid == 0) {
+            // last row r in [row_lo,row_hi) with row_ptr[r] <= o0: non-empty and contains output o0
+            int lo = row_lo, hi = row_hi;            // invariant: row_ptr[lo] <= o0 < row_ptr[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (row_ptr[mid] <= o0) lo = mid; else hi = mid;
+            }
+            r_first = lo;
+            // ... and the row that holds the chunk's last output
+            lo = r_first, hi = row_hi;               // invariant: row_ptr[lo] <= o1 - 1 < row_ptr[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (row_ptr[mid] <= o1 - 1) lo = mid; else hi = mid;
+            }
+            r_last = lo;
         }
-        r_first = lo;
-        // ... and the row that holds the chunk's last output
-        lo = r_first, hi = row_hi;               // invariant: row_ptr[lo] <= o1 - 1 < row_ptr[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (row_ptr[mid] <= o1 - 1) lo = mid; else hi = mid;
-        }
-        r_last = lo;
+        __syncthreads();
+        rf = r_first;
+        rl = r_last;
     }
-    __syncthreads();
-    if (r_last - r_first > kCompactSparseRows) {
+    if (rl - rf > kCompactSparseRows) {
         // Mostly empty rows (a masked product, a very sparse result): staging every row of the span
         // through LDS would walk millions of empty rows in ONE workgroup.  Search per output instead.
-        const int rf = r_first, rl = r_last;
         for (long long o = o0 + tid; o < o1; o += 256) {
             int lo = rf, hi = rl + 1;            // row_ptr[lo] <= o < row_ptr[hi]
             while (hi - lo > 1) {
@@ -416,13 +421,16 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
         }
         return;
     }
-    int rbase = r_first;
+    int rbase = rf;
     while (true) {
-        const int nb = (row_hi - rbase < kCompactBatch) ? row_hi - rbase : kCompactBatch;   // rows staged
+        // rows staged: up to the chunk's last row (row_ptr[rl + 1] >= o1 ends the loop below), a batch at a time
+        const int nb = (rl + 1 - rbase < kCompactBatch) ? rl + 1 - rbase : kCompactBatch;
         __syncthreads();
-        for (int t = tid; t <= nb; t += 256) rp[t] = row_ptr[rbase + t];
-        __syncthreads();
-        for (int t = tid; t < nb; t += 256) sh[t] = Fprefix[rbase + t] - rp[t];
+        for (int t = tid; t <= nb; t += 256) {                   // both loads of a row in one round trip
+            const long long start = row_ptr[rbase + t];
+            rp[t] = start;
+            if (t < nb) sh[t] = Fprefix[rbase + t] - start;
+        }
         __syncthreads();
         const long long b0 = rp[0] > o0 ? rp[0] : o0;          // outputs covered by this batch and chunk
         const long long b1 = rp[nb] < o1 ? rp[nb] : o1;
