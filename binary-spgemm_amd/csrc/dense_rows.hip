@@ -348,14 +348,14 @@ void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recp
 // Compaction: every row was written at its upper-bound offset Fprefix[r]; now that the counts
 // are scanned into C.row_ptr the rows are copied to their final place.  Pure streaming copy
 // (4 B read + 4 B written per output nonzero), driven by the DESTINATION: a workgroup owns
-// 8192 consecutive output nonzeros (32 KiB of C.col_idx), takes the rows that cover them from the
+// 4096 consecutive output nonzeros (16 KiB of C.col_idx), takes the rows that cover them from the
 // table the count scan left (chunk_row: the row of every 4096th output; without the table -- small
 // products -- 32768 outputs or fewer and a binary search in C.row_ptr), keeps their (row_ptr, shift) pairs in LDS 256 rows at a time and
 // copies 16 B per lane whenever four outputs lie in one row -- stores are always 16-B aligned
 // and fully coalesced, loads are the same stream displaced by the row's shift.  Work per
 // workgroup is fixed whatever the row lengths (hub rows and empty rows cost nothing extra).
 constexpr int kCompactChunk = 32768;     // output nonzeros per workgroup when its rows are searched (a small product gets smaller chunks: see launch_compact)
-constexpr int kCompactChunkTable = 8192; // ... when the count scan left the row table (chunk_row): a multiple of kCompactGran
+constexpr int kCompactChunkTable = 4096; // ... when the count scan left the row table (chunk_row): a multiple of kCompactGran
 static_assert(kCompactChunkTable % kCompactGran == 0, "chunk starts must be entries of the row table");
 constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
 constexpr int kCompactInFlight = 4;      // 16-B groups a thread has in flight (8 measured slower)
@@ -464,13 +464,23 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                     const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
                     __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
                 } else if (live[u]) {
+                    // a group that straddles rows (or the batch / chunk end): its outputs one by one -- the four loads
+                    // first, then the stores (one round trip: nearly every wave has such a group)
                     int r = lo_r[u];
+                    int val[4];
+                    bool has[4];
+#pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const long long oe = o[u] + e;
-                        if (oe < b0 || oe >= b1) continue;
-                        while (rp[r + 1] <= oe) r++;
-                        col_idx[oe] = tmp[oe + sh[r]];
+                        has[e] = oe >= b0 && oe < b1;
+                        if (has[e]) {
+                            while (rp[r + 1] <= oe) r++;
+                            val[e] = tmp[oe + sh[r]];
+                        }
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (has[e]) col_idx[o[u] + e] = val[e];
                 }
             }
         }
@@ -484,9 +494,10 @@ void launch_compact(const int *tmp, const long long *Fprefix, const long long *r
 {
     if (row_hi <= row_lo || max_out <= 0) return;
     // chunk: a multiple of 4 outputs (aligned 16-B stores).  With the scan's row table a workgroup's set-up is two
-    // loads instead of two binary searches in C.row_ptr, and smaller chunks pay: 8192 outputs (32 KiB) measured best
-    // (stitch phase on the bench matrix 2.35 ms searched at 32768; with the table 2.24 at 32768, 2.18 at 16384,
-    // 2.16 at 8192, 2.30 at 4096; power-law 2.85 -> 2.56: `profiles/r03_ab_compaction.log`).  A small product is
+    // loads instead of two binary searches in C.row_ptr, and smaller chunks pay (stitch phase on the bench matrix:
+    // 2.35 ms searched at 32768 outputs per workgroup; with the table 2.24 at 32768, 2.18 at 16384, 2.16 at 8192; with
+    // the lighter prologue of the final kernel 2.10 at 8192 and 2.11 at 4096, power-law 2.85 -> 2.69 -> 2.43:
+    // `profiles/r03_ab_compaction.log`): 4096 outputs (16 KiB).  A small product is
     // cut finer still so that it spreads over the chip (one large chunk would be ONE workgroup walking every row);
     // those chunks are not multiples of the table's grain and are searched.
     long long chunk = ((max_out / 2048) + 3) & ~3ll;
