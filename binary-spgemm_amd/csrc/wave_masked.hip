@@ -254,7 +254,7 @@ void k_wave_masked(const int2 *__restrict__ ab, const int *__restrict__ Bcol, in
             }
         }
         wave_lds_fence();
-        for (int t = lane; t < running; t += 64) out[t] = (int)L0w[stage_swz(t)];
+        for (int t = lane; t < running; t += 64) __builtin_nontemporal_store((int)L0w[stage_swz(t)], out + t);   // streamed, as in wave_rows.inc
         if (lane == 0) cnt[i - row_begin] = running;
         wave_lds_fence();
     }
