@@ -413,12 +413,20 @@ def main():
     # per-step HIP-event brackets recorded on the library's streams DURING the timed region
     hist = [ctx.stats(age) for age in range(min(args.steps, MAX_STAT_STEPS))]
     st = hist[0]
+    # the per-class brackets are OFF in the timed steps (an event pair around each of the ~17 class launches costs
+    # about 1 %): two extra, untimed steps with them on itemise the classes (roofline.instances)
+    ctx.set_class_timing(True)
+    for _ in range(2):
+        rotate()
+    fence()
+    itemised = [ctx.stats(age) for age in range(2)]
+    ctx.set_class_timing(False)
     if older is not None:
         retire(older)
     keys = ("ms_total", "ms_symbolic", "ms_prepass", "ms_count", "ms_numeric", "ms_stitch")
     phase_ms = {k: float(np.mean([h[k] for h in hist])) for k in keys}
-    bin_ms = np.mean([h["ms_bin"] for h in hist], axis=0)
-    bin_count_ms = np.mean([h["ms_bin_count"] for h in hist], axis=0)
+    bin_ms = np.mean([h["ms_bin"] for h in itemised], axis=0)
+    bin_count_ms = np.mean([h["ms_bin_count"] for h in itemised], axis=0)
     if use_dist:
         rdev = torch.device("cpu") if shared_gpu else dev
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)

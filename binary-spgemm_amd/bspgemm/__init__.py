@@ -51,7 +51,7 @@ EXPORTS = [
     "bspgemm_matrix_from_result", "bspgemm_closure",
     "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
     "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
-    "bspgemm_set_flow", "bspgemm_build_info", "bspgemm_matrix_invalidate", "bspgemm_comm_agree", "bspgemm_comm_inject_failure",
+    "bspgemm_set_flow", "bspgemm_set_class_timing", "bspgemm_build_info", "bspgemm_matrix_invalidate", "bspgemm_comm_agree", "bspgemm_comm_inject_failure",
 ]
 
 
@@ -146,6 +146,7 @@ def lib():
     L.bspgemm_set_stream.argtypes = [VP, VP]
     L.bspgemm_synchronize.argtypes = [VP]
     L.bspgemm_set_flow.argtypes = [VP, C.c_int]
+    L.bspgemm_set_class_timing.argtypes = [VP, C.c_int]
     L.bspgemm_build_info.restype = C.c_char_p
     L.bspgemm_matrix_invalidate.argtypes = [VP]
     L.bspgemm_matrix_upload.argtypes = [VP, C.c_int, C.c_int, VP, VP, PVP]
@@ -325,6 +326,10 @@ class Context:
     def set_flow(self, flow):
         """"auto" | "upper-bound" | "exact" | "fused" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
         _chk(lib().bspgemm_set_flow(self._h, {"auto": 0, "upper-bound": 1, "exact": 2, "fused": 3}[flow]), "set_flow")
+
+    def set_class_timing(self, on):
+        """event brackets around every class launch (stats: ms_bin, t_bin, ...); off by default: they cost ~1 %"""
+        _chk(lib().bspgemm_set_class_timing(self._h, 1 if on else 0), "set_class_timing")
 
     def upload(self, row_ptr, col_idx, cols, row0=0, rows=None):
         """Host CSR -> device.  row0/rows select an interior row range (absolute row_ptr values)."""

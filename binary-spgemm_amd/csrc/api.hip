@@ -106,6 +106,7 @@ struct bspgemm_context {
         hipEvent_t ev[5] = {};                      // start / classes known / row sizes known / rows emitted / done
         hipEvent_t ev_cls[2][kNumBins][2] = {};     // per (phase, class): launch brackets
         int R = 0;
+        bool cls_timed = false;                     // the class brackets of this multiply were recorded
         int mid_cap = 0;
         HostScalars h = {};
         long long products = 0, nnz_c = 0;
@@ -151,6 +152,7 @@ struct bspgemm_context {
     size_t cache_budget = 0;            // bytes the cache may pin (a quarter of the device memory)
     int flow = BSPGEMM_FLOW_AUTO;       // bspgemm_set_flow / BSPGEMM_FLOW
     // environment knobs, read ONCE in bspgemm_create (include/bspgemm.h, "Environment")
+    bool class_timing = false;          // bspgemm_set_class_timing / BSPGEMM_CLASS_TIMING=1: an event pair around every class launch
     int class_streams = 2;              // BSPGEMM_CLASS_STREAMS: streams the class launches alternate over (measured: 2 -8 %, 3 no better)
     bool check = false;                 // BSPGEMM_CHECK: the exact flow never emits on unverified sizes
     int rw_blk = -1;                    // BSPGEMM_RW_BLK: 0 never / 1 always use the blocked extents table (default: per operand)
@@ -269,6 +271,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     if (const char *e = getenv("BSPGEMM_FLOW"))
         ctx->flow = !strcmp(e, "fused") ? BSPGEMM_FLOW_FUSED : !strcmp(e, "exact") ? BSPGEMM_FLOW_EXACT : (!strcmp(e, "upper-bound") || !strcmp(e, "ub")) ? BSPGEMM_FLOW_UPPER_BOUND
                                                                                                                : BSPGEMM_FLOW_AUTO;
+    if (const char *e = getenv("BSPGEMM_CLASS_TIMING")) ctx->class_timing = atoi(e) != 0;
     if (const char *e = getenv("BSPGEMM_CLASS_STREAMS")) { const int n = atoi(e); ctx->class_streams = n < 1 ? 1 : (n > 3 ? 3 : n); }
     ctx->check = getenv("BSPGEMM_CHECK") != nullptr;
     if (const char *e = getenv("BSPGEMM_RW_BLK")) ctx->rw_blk = atoi(e) ? 1 : 0;
@@ -636,6 +639,7 @@ static void close_slot(bspgemm_context *ctx, int R, const HostScalars *h, long l
 {
     bspgemm_context::StatSlot &sl = ctx->slots[ctx->slot_head];
     sl.R = R;
+    sl.cls_timed = ctx->class_timing;
     sl.mid_cap = mid_cap;
     sl.h = *h;
     sl.products = products;
@@ -668,7 +672,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     hipEventElapsedTime(&st.ms_stitch, sl.ev[3], sl.ev[4]);
     for (int ph = 0; ph < 2; ph++)
         for (int b = 1; b < kNumBins; b++)
-            if (sl.cls_n[ph][b] > 0) {
+            if (sl.cls_n[ph][b] > 0 && sl.cls_timed) {
                 float ms = 0, t0 = 0;
                 hipEventElapsedTime(&ms, sl.ev_cls[ph][b][0], sl.ev_cls[ph][b][1]);
                 hipEventElapsedTime(&t0, sl.ev[0], sl.ev_cls[ph][b][0]);
@@ -760,7 +764,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             if (n <= 0) continue;
             hipStream_t sx = lanes[pos % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b];
-            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
             if (b <= kWaveBins) {
                 // the numeric kernel without its emit half: |C_i| = F_i as soon as every product is seen to sit alone
                 // in its 32-column slot, the level-0 masks are only built and counted for the other rows
@@ -772,7 +776,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
                 HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
-            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
         }
         HIPCHK_B(hipGetLastError());
         for (int l = 1; l < nlanes; l++) HIPCHK_B(join(l, ctx->ev_tile[0][l]));
@@ -813,13 +817,13 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             const long long *recpre = ctx->recpre + bin_start[b];
             // the heavy rows' move runs beside the class launches on the third stream
             hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
-            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
                                  C->d_col_idx, nullptr, sx);
             else
                 launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
-            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
         }
         HIPCHK_B(hipGetLastError());
         for (int l = 1; l < nlanes; l++) HIPCHK_B(join(l, ctx->ev_tile[1][l]));
@@ -921,12 +925,12 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
             HIPCHK_B(hipStreamWaitEvent(sx, ctx->ev_tile[0][0], 0));
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *hpre = ctx->recpre + bin_start[b];
-            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
             hub_order(ctx, b, n, rec, hpre, sx);
             launch_extents_of_rows(rec, n, A->d_col_idx, B->d_row_ptr, ctx->ab, sx);
             HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
                                        row_begin, ctx->tmp, ctx->cnt, sx));
-            HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
             HIPCHK_B(hipEventRecord(ctx->ev_tile[0][1 + k], sx));
             HIPCHK_B(hipStreamWaitEvent(s, ctx->ev_tile[0][1 + k], 0));
         }
@@ -964,9 +968,9 @@ static bspgemm_status multiply_fused(bspgemm_context *ctx, const bspgemm_matrix 
         ta.col_idx = C->d_col_idx;
         ta.col_bits = col_bits;
         cls_n[1][1] = ntiles;
-        HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][0], s));
+        if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][0], s));
         HIPCHK_B(launch_tile_rows(levels, ta, grid, s));
-        HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][1], s));
+        if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][1][1], s));
         HIPCHK_B(hipMemcpyAsync(&h->chain_err, ta.err, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     } else {
         HIPCHK_B(hipMemsetAsync(C->d_row_ptr, 0, sizeof(long long), s));
@@ -1074,7 +1078,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             hipStream_t sx = lanes[pos % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
-            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
@@ -1088,7 +1092,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             else
                 HIPCHK_B(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
                                                   ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
-            HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
+            if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
         }
         HIPCHK_B(hipGetLastError());
         for (int l = 1; l < nlanes; l++) {
@@ -1139,6 +1143,13 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
         st = multiply_exact(ctx, A, B, row_begin, row_end, out);
     }
     return st;
+}
+
+extern "C" bspgemm_status bspgemm_set_class_timing(bspgemm_context *ctx, int on)
+{
+    if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "set_class_timing");
+    ctx->class_timing = on != 0;
+    return BSPGEMM_OK;
 }
 
 extern "C" bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow)

@@ -65,7 +65,7 @@ const char *bspgemm_build_info(void);
  * default flow additionally keeps a workspace of F entries (F = products), i.e. about 2F ints live
  * per context after a multiply (10.7 GB for BASELINE config 3).  bspgemm_destroy releases all.
  * Environment (read once, in bspgemm_create): BSPGEMM_FLOW=auto|upper-bound|exact|fused,
- * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_DEBUG_ALLOC,
+ * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_DEBUG_ALLOC,
  * BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.                             */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
@@ -129,6 +129,12 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
 #define BSPGEMM_FLOW_FUSED       3
 bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow);
 
+/* Per-class launch brackets (bspgemm_stats: ms_bin, ms_bin_count, t_bin, t_bin_count).  OFF by default (or env
+ * BSPGEMM_CLASS_TIMING=1): an event pair around each of a multiply's ~17 class launches keeps consecutive
+ * launches of a stream apart (measured: +0.06 ms on BASELINE config 3).  The phase times (ms_prepass ..
+ * ms_stitch) are always recorded.  A profiling pass switches this on for the multiplies it wants itemised. */
+bspgemm_status bspgemm_set_class_timing(bspgemm_context *ctx, int on);
+
 /* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):
  * a column k is admitted to row i only if (i,k) is in F's pattern.                           */
 bspgemm_status bspgemm_multiply_masked(bspgemm_context *ctx,
@@ -189,7 +195,7 @@ typedef struct bspgemm_stats {
     float   ms_numeric;      /* accumulate + emit kernels, rows written at their final place */
     float   ms_stitch;       /* what is left exposed after them (heavy-row move; masked
                                 product: count scan + compaction)                            */
-    float   ms_bin[BSPGEMM_MAX_BINS];       /* per class: its numeric-phase launch           */
+    float   ms_bin[BSPGEMM_MAX_BINS];       /* per class: its numeric-phase launch (0 unless bspgemm_set_class_timing) */
     float   ms_bin_count[BSPGEMM_MAX_BINS]; /* per class: its symbolic-phase (count) launch  */
     float   t_bin[BSPGEMM_MAX_BINS];        /* ... and when those launches STARTED, in ms    */
     float   t_bin_count[BSPGEMM_MAX_BINS];  /*     since the multiply began (the class launches

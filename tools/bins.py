@@ -6,6 +6,7 @@ import numpy as np
 import torch, bspgemm
 which = sys.argv[1] if len(sys.argv) > 1 else "powerlaw"
 ctx = bspgemm.Context(0)
+ctx.set_class_timing(True)
 if len(sys.argv) > 2:
     ctx.set_flow(sys.argv[2])
 if which == "rmat22":

@@ -2,6 +2,7 @@ import sys, time
 sys.path.insert(0, "binary-spgemm_amd")
 import torch, bspgemm
 ctx = bspgemm.Context(0)
+ctx.set_class_timing(True)
 for scale, abc in ((20, (0.30, 0.25, 0.25)), (22, (0.30, 0.25, 0.25)), (18, (0.57, 0.19, 0.19))):
     rp, ci, n = bspgemm.gen_rmat(scale, 16, abc, seed=1)
     A = ctx.upload(rp, ci, n)

@@ -2,6 +2,7 @@ import sys
 sys.path.insert(0, "binary-spgemm_amd")
 import torch, bspgemm
 ctx = bspgemm.Context(0)
+ctx.set_class_timing(True)
 rp, ci, n = bspgemm.gen_rmat(22, 16, (0.30, 0.25, 0.25), seed=1)
 A = ctx.upload(rp, ci, n)
 for i in range(4):
