@@ -421,6 +421,13 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
         }
         return;
     }
+    // From here on positions are ints RELATIVE to the chunk's (unclipped, 16-B aligned) start: row starts are clamped to
+    // [0, chunk] (a row that begins before the chunk compares like 0, one that begins after it like `chunk`), the row's
+    // shift carries the chunk start, so that a group's source is one 64-bit add.
+    const long long obase = (out_lo & ~3ll) + (long long)blockIdx.x * chunk;
+    const int o0r = (int)(o0 - obase), o1r = (int)(o1 - obase);
+    int *rpr = reinterpret_cast<int *>(rp);      // rp's storage, as ints
+    int *__restrict__ dst = col_idx + obase;
     int rbase = rf;
     while (true) {
         // rows staged: up to the chunk's last row (row_ptr[rl + 1] >= o1 ends the loop below), a batch at a time
@@ -428,30 +435,30 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
         __syncthreads();
         for (int t = tid; t <= nb; t += 256) {                   // both loads of a row in one round trip
             const long long start = row_ptr[rbase + t];
-            rp[t] = start;
-            if (t < nb) sh[t] = Fprefix[rbase + t] - start;
+            const long long rel = start - obase;
+            rpr[t] = rel < 0 ? 0 : (rel > chunk ? chunk : (int)rel);
+            if (t < nb) sh[t] = Fprefix[rbase + t] - start + obase;
         }
         __syncthreads();
-        const long long b0 = rp[0] > o0 ? rp[0] : o0;          // outputs covered by this batch and chunk
-        const long long b1 = rp[nb] < o1 ? rp[nb] : o1;
+        const int b0 = rpr[0] > o0r ? rpr[0] : o0r;            // outputs covered by this batch and chunk
+        const int b1 = rpr[nb] < o1r ? rpr[nb] : o1r;
         // kCompactInFlight 16-B groups per thread per step: independent row searches and loads in flight
-        for (long long g0 = (b0 >> 2) + tid; (g0 << 2) < b1; g0 += 256 * kCompactInFlight) {
-            long long o[kCompactInFlight], src[kCompactInFlight];
+        for (int g0 = (b0 >> 2) + tid; (g0 << 2) < b1; g0 += 256 * kCompactInFlight) {
+            int o[kCompactInFlight], lo_r[kCompactInFlight];
+            long long src[kCompactInFlight];
             bool fast[kCompactInFlight], live[kCompactInFlight];
-            int lo_r[kCompactInFlight];
 #pragma unroll
             for (int u = 0; u < kCompactInFlight; u++) {
-                const long long g = g0 + u * 256;
-                o[u] = g << 2;
+                o[u] = (g0 + u * 256) << 2;
                 live[u] = o[u] < b1;
-                const long long oo = !live[u] ? b0 : (o[u] > b0 ? o[u] : b0);
-                int lo = 0, hi = nb;             // rp[lo] <= oo < rp[hi]
+                const int oo = !live[u] ? b0 : (o[u] > b0 ? o[u] : b0);
+                int lo = 0, hi = nb;             // rpr[lo] <= oo < rpr[hi]
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
-                    if (rp[mid] <= oo) lo = mid; else hi = mid;
+                    if (rpr[mid] <= oo) lo = mid; else hi = mid;
                 }
                 lo_r[u] = lo;
-                fast[u] = live[u] && o[u] >= b0 && o[u] + 3 < b1 && o[u] + 3 < rp[lo + 1];
+                fast[u] = live[u] && o[u] >= b0 && o[u] + 3 < b1 && o[u] + 3 < rpr[lo + 1];
                 src[u] = o[u] + sh[lo];
             }
             Int4U v[kCompactInFlight];
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
             for (int u = 0; u < kCompactInFlight; u++) {
                 if (fast[u]) {
                     const v4i w4 = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(col_idx + o[u]));
+                    __builtin_nontemporal_store(w4, reinterpret_cast<v4i *>(dst + o[u]));
                 } else if (live[u]) {
                     // a group that straddles rows (or the batch / chunk end): its outputs one by one -- the four loads
                     // first, then the stores (one round trip: nearly every wave has such a group)
@@ -471,20 +478,20 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
                     bool has[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        const long long oe = o[u] + e;
+                        const int oe = o[u] + e;
                         has[e] = oe >= b0 && oe < b1;
                         if (has[e]) {
-                            while (rp[r + 1] <= oe) r++;
+                            while (rpr[r + 1] <= oe) r++;
                             val[e] = tmp[oe + sh[r]];
                         }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        if (has[e]) col_idx[o[u] + e] = val[e];
+                        if (has[e]) dst[o[u] + e] = val[e];
                 }
             }
         }
-        if (rp[nb] >= o1 || rbase + nb >= row_hi) break;       // uniform: every thread reads the same LDS
+        if (rpr[nb] >= o1r || rbase + nb >= row_hi) break;     // uniform: every thread reads the same LDS
         rbase += nb;
     }
 }
