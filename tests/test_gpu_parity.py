@@ -239,6 +239,25 @@ def test_tuning_knobs_do_not_change_results(ctx, env):
     assert_same(crp, cci, erp, eci)
 
 
+def test_class_timing_switch(ctx):
+    """per-class event brackets are off by default (they cost ~1 % of a large product), on request the stats carry them;
+    the result is the same either way and the phase times are always there"""
+    rp, ci, n = gen.rmat(13, 16, (0.57, 0.19, 0.19, 0.05), 11)
+    A = ctx.upload(rp, ci, n)
+    C = ctx.multiply(A, A); ref = C.download(); C.free()
+    st = ctx.stats()
+    assert float(np.sum(st["ms_bin"])) == 0.0 and st["ms_numeric"] > 0 and st["ms_total"] > 0
+    ctx.set_class_timing(True)
+    try:
+        C = ctx.multiply(A, A); got = C.download(); C.free()
+        st = ctx.stats()
+        # (the fused flow launches one kernel for all one-wave classes: only the total is meaningful there)
+        assert float(np.sum(st["ms_bin"])) + float(np.sum(st["ms_bin_count"])) > 0.0
+    finally:
+        ctx.set_class_timing(False)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
 def test_blocked_extents_table_forced(ctx):
     """k_row_work_blk (csrc/prepass.hip) is chosen per operand only for B of 2^21 rows or more; forced here on
     small shapes that hit every branch of it: rows of 255+ nonzeros (clamped bytes -> exact lookup), a block
