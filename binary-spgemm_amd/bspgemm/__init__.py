@@ -52,6 +52,7 @@ EXPORTS = [
     "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
     "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
     "bspgemm_set_flow", "bspgemm_set_class_timing", "bspgemm_build_info", "bspgemm_matrix_invalidate", "bspgemm_comm_agree", "bspgemm_comm_inject_failure",
+    "bspgemm_set_option", "bspgemm_get_option", "bspgemm_matrix_uses_blocked_table",
 ]
 
 
@@ -63,6 +64,8 @@ class BspgemmError(RuntimeError):
 
 
 MAX_BINS = 20      # BSPGEMM_MAX_BINS
+FLOWS = {"auto": 0, "upper-bound": 1, "exact": 2}                                    # BSPGEMM_FLOW_*
+OPTIONS = {"class_streams": 1, "blocked_extents": 2, "check": 3, "small_path": 4}    # bspgemm_option
 
 
 class Stats(C.Structure):
@@ -72,7 +75,8 @@ class Stats(C.Structure):
                 ("ms_count", C.c_float), ("ms_numeric", C.c_float), ("ms_stitch", C.c_float),
                 ("ms_bin", C.c_float * MAX_BINS), ("ms_bin_count", C.c_float * MAX_BINS),
                 ("t_bin", C.c_float * MAX_BINS), ("t_bin_count", C.c_float * MAX_BINS), ("bins", C.c_int),
-                ("bin_cap", C.c_int * MAX_BINS)]
+                ("bin_cap", C.c_int * MAX_BINS), ("flow", C.c_int), ("prepass_kernel", C.c_int),
+                ("class_streams", C.c_int), ("small_path", C.c_int), ("checked", C.c_int)]
 
     def as_dict(self):
         arrays = ("rows_per_bin", "ms_bin", "ms_bin_count", "t_bin", "t_bin_count", "bin_cap")
@@ -149,6 +153,9 @@ def lib():
     L.bspgemm_set_class_timing.argtypes = [VP, C.c_int]
     L.bspgemm_build_info.restype = C.c_char_p
     L.bspgemm_matrix_invalidate.argtypes = [VP]
+    L.bspgemm_set_option.argtypes = [VP, C.c_int, C.c_int]
+    L.bspgemm_get_option.argtypes = [VP, C.c_int]
+    L.bspgemm_matrix_uses_blocked_table.argtypes = [VP]
     L.bspgemm_matrix_upload.argtypes = [VP, C.c_int, C.c_int, VP, VP, PVP]
     L.bspgemm_matrix_wrap_device.argtypes = [VP, C.c_int, C.c_int, C.c_int64, VP, VP, PVP]
     L.bspgemm_matrix_free.argtypes = [VP]
@@ -324,8 +331,15 @@ class Context:
         _chk(lib().bspgemm_synchronize(self._h), "synchronize")
 
     def set_flow(self, flow):
-        """"auto" | "upper-bound" | "exact" | "fused" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
-        _chk(lib().bspgemm_set_flow(self._h, {"auto": 0, "upper-bound": 1, "exact": 2, "fused": 3}[flow]), "set_flow")
+        """"auto" | "upper-bound" | "exact" (BSPGEMM_FLOW_*, include/bspgemm.h)"""
+        _chk(lib().bspgemm_set_flow(self._h, FLOWS[flow]), "set_flow")
+
+    def set_option(self, name, value):
+        """bspgemm_set_option: "class_streams" 1..3, "blocked_extents" -1/0/1, "check" 0/1, "small_path" -1/0/1"""
+        _chk(lib().bspgemm_set_option(self._h, OPTIONS[name], int(value)), "set_option(%s)" % name)
+
+    def get_option(self, name):
+        return lib().bspgemm_get_option(self._h, OPTIONS[name])
 
     def set_class_timing(self, on):
         """event brackets around every class launch (stats: ms_bin, t_bin, ...); off by default: they cost ~1 %"""
@@ -401,6 +415,15 @@ class Matrix:
         self.rows = lib().bspgemm_matrix_rows(handle)
         self.cols = lib().bspgemm_matrix_cols(handle)
         self.nnz = lib().bspgemm_matrix_nnz(handle)
+
+    def invalidate(self):
+        """bspgemm_matrix_invalidate: the wrapped device arrays were rewritten in place; derived tables are rebuilt"""
+        _chk(lib().bspgemm_matrix_invalidate(self._h), "matrix_invalidate")
+
+    @property
+    def uses_blocked_table(self):
+        """1 / 0 once the operand has been used as B (which prepass kernel it gets), -1 before"""
+        return lib().bspgemm_matrix_uses_blocked_table(self._h)
 
     def free(self):
         if self._h:

@@ -1,6 +1,6 @@
 // kernels.hpp -- launch wrappers of the HIP kernels behind bspgemm_multiply (host-callable).
 // Kernel bodies: prepass.hip (row work, scans, class records), wave_rows.inc (+ wave_rows_L*.hip),
-// wave_masked.hip, dense_rows.hip (heavy rows + compaction), pack_tiles.hip + tile_rows.inc (fused flow).
+// wave_masked.hip, dense_rows.hip (heavy rows + compaction).
 // Tuning constants are compile-time constants, not switches: what was tried against them is in profiles/.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -126,9 +126,16 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
 // tmp + row_ptr[i - row_begin] (tmp = C.col_idx, sizes known from the symbolic phase, cnt may be
 // NULL); row_ptr == NULL: at its upper-bound offset tmp + recpre[k], |C_i| to cnt (masked product)
 // count_only: the symbolic twin of the same kernel -- nothing is emitted (tmp, recpre, row_ptr unused), cnt[i] = |C_i|
+// err (device, never NULL): bit 0 is set when a row's gathered product count exceeds its class capacity -- impossible
+// for consistent operands (the classes come from the same extents), seen only when an operand was rewritten under
+// the library; the row is then truncated to its capacity instead of overrunning LDS
+constexpr unsigned kErrCapacity = 1u;     // a row gathered more products than its capacity class holds
+constexpr unsigned kErrStaleTable = 2u;   // an operand's derived tables do not match its row_ptr (bspgemm_matrix_invalidate)
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
-                      int row_begin, int *tmp, int *cnt, hipStream_t s, bool count_only = false);
+                      int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false);
+// debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] (either may be NULL) against row_ptr; sets kErrStaleTable in *err
+void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s);
 
 // heavy rows: workspace -> final place (one workgroup per heavy row)
 void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,
@@ -162,51 +169,6 @@ void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int
 // product count) only sizes the grid.
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
                     int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s, const int *chunk_row = nullptr);
-
-// ---- fused flow: tiles of consecutive rows, one persistent kernel, rows written once -------------
-// a tile = rows [row0, row0 + nrows) of the multiplied range (row0 relative to row_begin)
-struct TileDesc {
-    int row0;
-    unsigned nrf;   // bits 0..7 rows in the tile (1..64), bits 8..27 its products (0 for a heavy row), bit 31 heavy row
-    int a0;         // A.row_ptr[row_begin + row0]
-    int nsrc;       // A-nonzeros of the tile's rows
-};
-constexpr int kTileCap = 2048;           // products per tile = capacity of the workgroup's accumulator
-// rows per tile allowed by the key width: a tile's accumulator holds (local row, column) keys
-int tile_levels_for(int cols, long long est_rows_per_tile, int cap, int *row_bits, int *col_bits);
-// pass 1 of the packer (pack_tiles.hip): marks8 = tile starts, tile_count/bound per 2048 rows,
-// totals[0] = number of tiles, totals[1] = sum of min(F_i, cols); tile_count becomes each block's first tile
-void launch_pack_tiles_count(const long long *F, int n, int cap, int maxr, int cols, unsigned char *marks8,
-                             int *tile_count, long long *bound, long long *totals, hipStream_t s);
-// pass 2: the descriptors (Arow = A.row_ptr + row_begin)
-void launch_pack_tiles_emit(const long long *F, int n, int cap, int maxr, const int *Arow, const unsigned char *marks8,
-                            const int *tile_base, TileDesc *tiles, hipStream_t s);
-struct TileArgs {
-    const int *Arow;            // A.row_ptr + row_begin
-    const int *Acol;
-    const int *Brow;
-    const int *Bblk;            // B's blocked extents table, or NULL: B.row_ptr pairs are gathered
-    const int *Bcol;
-    const TileDesc *tiles;
-    int ntiles;
-    int nrows;                  // rows multiplied (R)
-    const int *cnt;             // |C_i| of the heavy rows (computed before the launch)
-    // the chain (all zeroed before the launch): a tile's size, valid bit on top; per block of 64 tiles an
-    // accumulator (count << 56 | sum) and the inclusive total through the block once somebody knows it
-    unsigned *tdesc;
-    unsigned long long *bacc;
-    unsigned long long *binc;
-    unsigned *ticket;           // tile counters, one per shard, 32 words apart (zeroed before the launch)
-    int nshards;                // 8: tiles dealt round-robin to the XCDs; 1: one counter
-    unsigned *err;              // set when a look-back wait ran out (zeroed before the launch)
-    long long *row_ptr;         // C.row_ptr (R + 1)
-    int *col_idx;               // C.col_idx
-    int col_bits;               // key = (local row << col_bits) | column
-};
-// persistent kernel: `grid` workgroups; returns hipErrorInvalidValue for an unsupported level count
-hipError_t launch_tile_rows(int levels, const TileArgs &a, int grid, hipStream_t s);
-// workgroups of the tile kernel that fit the device at once (per level count)
-int tile_rows_grid(int levels, int device);
 
 // int64 row_ptr -> int32 (operand form of a product)
 void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);

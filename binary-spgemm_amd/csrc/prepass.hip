@@ -269,6 +269,31 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ Ar
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
+// Debug check behind BSPGEMM_OPT_CHECK: an operand's derived tables against its row_ptr.  A caller that rewrote a
+// wrapped operand in place without bspgemm_matrix_invalidate would otherwise size rows from old lengths.
+__global__ __launch_bounds__(256) void k_check_tables(const int *__restrict__ row_ptr, int n,
+                                                      const unsigned char *__restrict__ deg8, const int *__restrict__ blk,
+                                                      unsigned *__restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = row_ptr[i + 1] - row_ptr[i];
+    const unsigned want = (unsigned)(d < 255 ? d : 255);
+    bool bad = d < 0;
+    if (deg8) bad = bad || deg8[i] != want;
+    if (blk) {
+        const int b = i >> 3, k = i & 7;
+        const unsigned w = (unsigned)blk[3 * b + 1 + (k >> 2)];
+        bad = bad || ((w >> (8 * (k & 3))) & 255u) != want || (k == 0 && blk[3 * b] != row_ptr[i]);
+    }
+    if (bad) atomicOr(err, kErrStaleTable);
+}
+void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s)
+{
+    if (rows <= 0 || (!deg8 && !blk8)) return;
+    hipLaunchKernelGGL(k_check_tables, dim3((rows + 255) / 256), dim3(256), 0, s, row_ptr, rows, deg8, blk8, err);
+}
+
 void launch_row_products(const int *Arow, const int *Acol, const int *Brow, const unsigned char *Bdeg8,
                          int row_begin, int row_end, long long *F, hipStream_t s)
 {

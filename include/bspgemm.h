@@ -64,9 +64,10 @@ const char *bspgemm_build_info(void);
  * quarter of the device memory) and are handed to the next multiply instead of hipMalloc; the
  * default flow additionally keeps a workspace of F entries (F = products), i.e. about 2F ints live
  * per context after a multiply (10.7 GB for BASELINE config 3).  bspgemm_destroy releases all.
- * Environment (read once, in bspgemm_create): BSPGEMM_FLOW=auto|upper-bound|exact|fused,
- * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_DEBUG_ALLOC,
- * BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.                             */
+ * Environment (read once, in bspgemm_create; every knob also has a setter, bspgemm_set_option / _set_flow /
+ * _set_class_timing, which is what a running program uses): BSPGEMM_FLOW=auto|upper-bound|exact,
+ * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1,
+ * BSPGEMM_DEBUG_ALLOC, BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.          */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
 typedef struct bspgemm_result  bspgemm_result;    /* device-resident CSR product, int64 row_ptr */
@@ -116,17 +117,13 @@ bspgemm_status bspgemm_multiply(bspgemm_context *ctx,
  *   EXACT        a symbolic pass sizes every row exactly first (the accumulate kernels without their emit half), C.row_ptr
  *                is their scan, and the numeric pass emits every row at its final place: nnz(C)
  *                entries, no F-sized workspace.
- *   FUSED        rows are accumulated in ROW ORDER by tiles of consecutive rows in one persistent kernel;
- *                a tile's place is the total of the tiles before it (look-back chain), every row is
- *                written once, at its final place: no workspace, no count pass -- the reference's own
- *                order of events (final/SpGEMM_mpi_omp.c:28-42).  Opt-in: measured slower than the
- *                other two on large products.
- *   AUTO         (default, or env BSPGEMM_FLOW=auto|upper-bound|exact|fused) UPPER_BOUND, and EXACT when
- *                its buffers cannot be allocated.                                               */
+ *   AUTO         (default, or env BSPGEMM_FLOW=auto|upper-bound|exact) UPPER_BOUND, and EXACT when its
+ *                buffers cannot be allocated.
+ * (Round 3 also shipped a third, row-ordered single-pass flow, "FUSED"; it was 4x slower on large products
+ * and was taken out in round 4 -- DESIGN.md section 2.1 keeps its measurements.)                  */
 #define BSPGEMM_FLOW_AUTO        0
 #define BSPGEMM_FLOW_UPPER_BOUND 1
 #define BSPGEMM_FLOW_EXACT       2
-#define BSPGEMM_FLOW_FUSED       3
 bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow);
 
 /* Per-class launch brackets (bspgemm_stats: ms_bin, ms_bin_count, t_bin, t_bin_count).  OFF by default (or env
@@ -134,6 +131,33 @@ bspgemm_status bspgemm_set_flow(bspgemm_context *ctx, int flow);
  * launches of a stream apart (measured: +0.06 ms on BASELINE config 3).  The phase times (ms_prepass ..
  * ms_stitch) are always recorded.  A profiling pass switches this on for the multiplies it wants itemised. */
 bspgemm_status bspgemm_set_class_timing(bspgemm_context *ctx, int on);
+
+/* The remaining tuning knobs as calls (the environment variables of the same names are only their initial
+ * values).  None of them changes a result, only which kernels produce it -- and bspgemm_stats says which did
+ * (prepass_kernel, class_streams, flow, small_path), so that a test can tell that the path it asked for ran.
+ *   CLASS_STREAMS    1..3  HIP streams the capacity-class launches of a phase alternate over (default 2)
+ *   BLOCKED_EXTENTS  -1 decide per operand (default: B of 2^21 rows or more and not dominated by rows of
+ *                    255+ nonzeros), 0 never, 1 always: whether the prepass gathers B's blocked extents table
+ *                    instead of B.row_ptr pairs.  Decided when an operand is first used as B, so set it
+ *                    before that (or call bspgemm_matrix_invalidate on the operand).
+ *   CHECK            0/1   debug checks: the exact flow never emits on unverified sizes, and the accumulate
+ *                    kernels verify each row's gathered product count against its capacity class (a stale
+ *                    derived table -- see bspgemm_matrix_invalidate -- then fails the multiply with
+ *                    BSPGEMM_ERR_INVALID instead of overrunning LDS)
+ *   SMALL_PATH       -1 automatic (default: products of at most 65536 with a cached result buffer take the
+ *                    single-launch path), 0 never, 1 whenever the product fits it                       */
+typedef enum bspgemm_option {
+    BSPGEMM_OPT_CLASS_STREAMS   = 1,
+    BSPGEMM_OPT_BLOCKED_EXTENTS = 2,
+    BSPGEMM_OPT_CHECK           = 3,
+    BSPGEMM_OPT_SMALL_PATH      = 4
+} bspgemm_option;
+bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_option opt, int value);
+/* current value of a knob (INT32_MIN for an unknown option or a NULL context) */
+int            bspgemm_get_option(const bspgemm_context *ctx, bspgemm_option opt);
+/* 1 if products with `m` as B gather its blocked extents table, 0 if they gather B.row_ptr pairs, -1 if
+ * that has not been decided yet (the operand has not been used as B since it was created / invalidated) */
+int            bspgemm_matrix_uses_blocked_table(const bspgemm_matrix *m);
 
 /* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):
  * a column k is admitted to row i only if (i,k) is in F's pattern.                           */
@@ -204,6 +228,13 @@ typedef struct bspgemm_stats {
     int     bins;            /* classes in use, including [0] and the heavy class            */
     int     bin_cap[BSPGEMM_MAX_BINS];      /* products a row of class b may have (masked product:
                                 mask-row length); 0 for [0], INT32_MAX for the heavy class   */
+    /* which path produced the result (so that a test of a knob can assert that the knob took) */
+    int     flow;            /* BSPGEMM_FLOW_UPPER_BOUND or BSPGEMM_FLOW_EXACT: the flow that ran     */
+    int     prepass_kernel;  /* 0 k_row_work (B.row_ptr pairs), 1 k_row_work_blk (blocked extents table),
+                                2 the single-launch small path's own prepass                          */
+    int     class_streams;   /* streams the class launches alternated over                           */
+    int     small_path;      /* 1: the single-launch path for small products ran                      */
+    int     checked;         /* 1: the device-side capacity guard was armed (BSPGEMM_OPT_CHECK)       */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
 /* ... and of earlier ones: age 0 = the last multiply, 1 = the one before, ... up to 15.  The
@@ -281,7 +312,11 @@ void           bspgemm_comm_destroy(bspgemm_comm *comm);
  * Every RCCL wait of this library is bounded (env BSPGEMM_COMM_TIMEOUT_S, default 120): on a timeout
  * or an asynchronous RCCL error the communicator is aborted and the call returns BSPGEMM_ERR_COMM.  */
 bspgemm_status bspgemm_comm_agree(bspgemm_comm *comm, bspgemm_status mine);
-/* test hook: 1 = the next SpGEMM_hip_multi on rank 0 behaves as if its host allocation had failed */
+/* After such a failure the communicator is DEAD: every later collective call on it (agree, stitch, gather,
+ * SpGEMM_hip_multi) returns BSPGEMM_ERR_COMM at once, without touching the transport; destroy it and build a new one.
+ * test hook (one-shot): 1 = the next SpGEMM_hip_multi on rank 0 behaves as if its host allocation had failed,
+ * 2 = the next bounded RCCL wait behaves as if it had run out (the communicator is aborted), 3 = the next growth of the
+ * stitch's staging buffers fails, 4 = the root's device buffer of the next RCCL col_idx gather cannot be allocated */
 void           bspgemm_comm_inject_failure(bspgemm_comm *comm, int what);
 int            bspgemm_comm_rank(const bspgemm_comm *comm);
 int            bspgemm_comm_size(const bspgemm_comm *comm);

@@ -10,7 +10,7 @@ import gen
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
-FLOWS = ("upper-bound", "exact", "fused", "auto")
+FLOWS = ("upper-bound", "exact", "auto")
 
 
 def _case(k, rng):
