@@ -7,8 +7,8 @@ C.row_ptr (the job of SpGEMM_mpi, reference final/SpGEMM_mpi_omp.c:155-225).  Th
 flow is timed (`roofline.flow` names it): products per row -> capacity classes -> rows accumulated and
 placed by their product count (an upper bound) -> counts scanned into C.row_ptr -> rows squeezed into
 C.col_idx (k_compact).  The north star's symbolic -> scan -> numeric order is the "exact" flow
-(BSPGEMM_FLOW=exact: 7.3 ms per step on this workload against 7.0) and the single-pass row-order
-"fused" flow is BSPGEMM_FLOW=fused (DESIGN.md section 2 has all three side by side).  The timed region
+(BSPGEMM_FLOW=exact: 6.9 ms per step on this workload against 6.3; round 3 also had a single-pass row-order
+"fused" flow, removed in round 4 -- DESIGN.md section 2 has all three side by side).  The timed region
 mirrors the reference's (:320-324): inputs resident, result allocation included, no file I/O --
 "allocation" here is a hit in the context's cache of freed results (config.allocation).
 
@@ -156,7 +156,7 @@ def bin_of(F, caps):
     return b
 
 
-def cpu_baseline(rp, ci, n, budget_s=6.0):
+def cpu_baseline(rp, ci, n, budget_s=6.0, gpu_ctx=None):
     """Reference CPU path -- the reference's own SpGEMM_omp compiled into oracle/_ref (kind
     "reference"; the in-repo port when that is absent) -- on bounded row samples of the same matrix,
     with the OpenMP team set explicitly (omp_set_num_threads) to 1, C/2 and C threads."""
@@ -216,23 +216,20 @@ def cpu_baseline(rp, ci, n, budget_s=6.0):
                                             best["tBlock"], best["seconds"]),
            "thread_sweep": sweep, "host_cpus": host_cpus, "usable_cpus": usable,
            "cpu_share": "%d cores = one GPU's share of this host; BSPGEMM_BENCH_CPU_CORES raises it" % C}
-    # ... and the reference's MPI + OpenMP program itself, the layout its report found fastest on a node
-    # (pure MPI, SURVEY.md 6 Fig. 8) included: the best of both is the baseline
+    # ... and the reference's MPI + OpenMP program itself, the layout its report found fastest on a node (pure MPI,
+    # SURVEY.md 6 Fig. 8).  It runs on an R-MAT scale-20 FILE (the reference's int32 counters and its loader bound the
+    # size), i.e. on ANOTHER matrix than `value` above and than the GPU headline: GNZ/s depends on the matrix, so the
+    # figure is kept in a field of its own and never folded into `value`; the GPU is timed on that same
+    # scale-20 matrix beside it (`gpu_same_matrix`) so that the ratio there is like for like.
     try:
-        mpi = cpu_baseline_mpirun(C) if kind == "reference" else None
+        mpi = cpu_baseline_mpirun(C, gpu_ctx) if kind == "reference" else None
     except Exception as e:
         mpi = {"error": repr(e)}
-    out["mpirun"] = mpi
-    if mpi and mpi.get("best") and mpi["best"]["GNZ/s"] > out["value"]:
-        b = mpi["best"]
-        out.update({"value": b["GNZ/s"], "cores": b["cores"],
-                    "layout": "mpirun -n %d x %d OpenMP threads (SpGEMM_mpi_omp binary)" % (b["P"], b["T"]),
-                    "sample": "%s; A*A, %d output nonzeros, median of 3 runs %.3f s (tBlock=%d)"
-                              % (mpi["matrix"], b["Cnnz"], b["median_s"], b["tBlock"])})
+    out["mpirun_other_workload"] = mpi
     return out
 
 
-def cpu_baseline_mpirun(budget_cores):
+def cpu_baseline_mpirun(budget_cores, gpu_ctx=None):
     """The reference BINARY as its README runs it -- `mpirun -n P SpGEMM_mpi_omp file tBlock T times`
     (final/SpGEMM_mpi_omp.c:294-366, README.md:12-21) -- built untouched into oracle/_ref, on an R-MAT scale-20
     file (the bench matrix's generator, a quarter of its rows: the reference's int32 counters and its loader,
@@ -283,9 +280,29 @@ def cpu_baseline_mpirun(budget_cores):
     if not ok:
         return {"runs": runs}
     best = max(ok, key=lambda r: r["GNZ/s"])
-    return {"best": best, "runs": runs, "matrix": "R-MAT scale %d (same generator and parameters), %d entries, file written in %.1f s"
-                                                 % (scale, int(rp[-1]), t_write),
-            "command": "mpirun -n P oracle/_ref/SpGEMM_mpi_omp <file> tBlock T 3"}
+    res = {"best": best, "runs": runs, "workload": "R-MAT scale %d, edge factor 16, (0.30,0.25,0.25,0.20), seed 1, A*A -- NOT the headline's "
+                                                   "scale-22 matrix" % scale,
+           "matrix": "R-MAT scale %d (same generator and parameters), %d entries, file written in %.1f s" % (scale, int(rp[-1]), t_write),
+           "command": "mpirun -n P oracle/_ref/SpGEMM_mpi_omp <file> tBlock T 3"}
+    if gpu_ctx is not None:
+        # the GPU on the SAME scale-20 matrix, operands resident, 10 multiplies after 3 warm-ups
+        try:
+            A = gpu_ctx.upload(rp, ci, n)
+            for _ in range(3):
+                gpu_ctx.multiply(A, A).free()
+            t = time.perf_counter()
+            nnz = 0
+            for _ in range(10):
+                Cg = gpu_ctx.multiply(A, A)
+                nnz = Cg.nnz
+                Cg.free()
+            dt = (time.perf_counter() - t) / 10
+            A.free()
+            res["gpu_same_matrix"] = {"ms_per_multiply": round(dt * 1e3, 4), "GNZ/s": round(nnz / dt / 1e9, 2), "nnz_c": int(nnz),
+                                      "ratio_to_best_mpirun_layout": round(nnz / dt / 1e9 / best["GNZ/s"], 1)}
+        except Exception as e:
+            res["gpu_same_matrix"] = {"error": repr(e)}
+    return res
 
 
 def pmc_profile(wname, world):
@@ -578,7 +595,7 @@ def main():
             out["dropin_e2e"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(rp, ci, n)
+            out["cpu_baseline"] = cpu_baseline(rp, ci, n, gpu_ctx=ctx)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
             out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:

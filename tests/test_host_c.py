@@ -8,6 +8,7 @@ import bspgemm
 import gen
 from oracle import oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -156,3 +157,32 @@ def test_generator_shapes():
     # draws are mean 64 per row; skewed column choice collapses many duplicates at small n
     assert deg.min() >= 1 and deg.max() <= n // 16 and 20 * n < rp[-1] <= 64 * n
     assert deg.max() > 20 * np.median(deg), "expected a heavy tail"
+
+
+def test_host_c_under_address_and_ub_sanitizers(tmp_path):
+    """the reference ships no sanitizer build.  oracle/Makefile builds the PRODUCT's host C (loader,
+    writers, generators, comparators, the drop-ins' host helpers) together with the restatement under
+    -fsanitize=address,undefined (asan/host_asan, CPU only) and this walks every entry point, including the loader's
+    rejection paths on ten malformed files; any report aborts the program."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "asan", "host_asan")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="4")
+    r = subprocess.run([exe, str(tmp_path), os.path.join(ROOT, "tests", "golden", "validity_test.mtx")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_asan ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr
+
+
+def test_powerlaw_generator_hits_the_requested_mean_degree():
+    """the generator drew deg_i columns per row ONCE and let duplicates collapse (mean 52 for a requested
+    64 at BASELINE config 5); rows are now topped up to deg_i DISTINCT columns"""
+    for n, d in ((1 << 14, 64), (20000, 24), (3000, 7)):
+        rp, ci, _ = bspgemm.gen_powerlaw(n, d, seed=3)
+        deg = np.diff(rp)
+        assert rp[-1] == n * d, (n, d, rp[-1] / n)
+        assert deg.min() >= 1 and deg.max() <= max(n // 16, 1)
+        for r in (0, n // 2, int(np.argmax(deg))):
+            row = ci[rp[r]:rp[r + 1]]
+            assert np.all(np.diff(row) > 0)                  # sorted, duplicate-free
