@@ -312,7 +312,15 @@ extern "C" bspgemm_status bspgemm_comm_stitch_row_ptr(bspgemm_comm *c, const bsp
         bspgemm_status st = c->inject == 3 ? FAIL(BSPGEMM_ERR_ALLOC, "staging buffers (injected)") : grow();
         if (c->inject == 3) c->inject = 0;
         st = bspgemm_comm_agree(c, st);
-        if (st) return st;
+        if (st) {
+            // EVERY rank forgets its staging buffers, also those whose allocation went through: the next stitch must find
+            // all ranks in this branch again (a rank that kept its buffers would skip the agree the others enter)
+            hipFree(c->d_send); hipFree(c->d_recv); hipFree(c->d_global);
+            c->d_send = c->d_recv = nullptr;
+            c->d_global = nullptr;
+            c->width_cap = c->global_cap = 0;
+            return st;
+        }
     }
     // 1. this shard's row lengths (pad slots are never read by the scan)
     if (my_rows > 0)

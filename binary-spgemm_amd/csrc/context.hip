@@ -117,6 +117,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     ctx->check = getenv("BSPGEMM_CHECK") != nullptr;
     if (const char *e = getenv("BSPGEMM_RW_BLK")) ctx->rw_blk = atoi(e) ? 1 : 0;
     if (const char *e = getenv("BSPGEMM_SMALL")) ctx->small = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("BSPGEMM_BUCKET")) ctx->bucket = atoi(e) != 0;
     ctx->debug_alloc = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
     ctx->dropin_timing = getenv("BSPGEMM_DROPIN_TIMING") != nullptr;
     if (ctx->debug_alloc)
@@ -421,6 +422,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     st.class_streams = sl.class_streams;
     st.small_path = sl.small ? 1 : 0;
     st.checked = sl.checked ? 1 : 0;
+    st.bucket_path = sl.bucket ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, sl.ev[0], sl.ev[4]);
     hipEventElapsedTime(&st.ms_prepass, sl.ev[0], sl.ev[1]);
     hipEventElapsedTime(&st.ms_count, sl.ev[1], sl.ev[2]);
@@ -464,6 +466,9 @@ extern "C" bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_optio
         if (value < -1 || value > 1) return FAIL(BSPGEMM_ERR_INVALID, "small path: -1, 0 or 1");
         ctx->small = value;
         return BSPGEMM_OK;
+    case BSPGEMM_OPT_BUCKET_PATH:
+        ctx->bucket = value != 0;
+        return BSPGEMM_OK;
     }
     return FAIL(BSPGEMM_ERR_INVALID, "unknown option");
 }
@@ -476,6 +481,7 @@ extern "C" int bspgemm_get_option(const bspgemm_context *ctx, bspgemm_option opt
     case BSPGEMM_OPT_BLOCKED_EXTENTS: return ctx->rw_blk;
     case BSPGEMM_OPT_CHECK: return ctx->check ? 1 : 0;
     case BSPGEMM_OPT_SMALL_PATH: return ctx->small;
+    case BSPGEMM_OPT_BUCKET_PATH: return ctx->bucket ? 1 : 0;
     }
     return INT_MIN;
 }

@@ -81,7 +81,7 @@ struct bspgemm_context {
         int cls_n[2][kNumBins] = {};
         bool used = false;
         int flow = 0, prepass_kernel = 0, class_streams = 0;   // which path ran (bspgemm_stats)
-        bool small = false, checked = false;
+        bool small = false, checked = false, bucket = false;
     };
     static constexpr int kStatSlots = 16;
     StatSlot slots[kStatSlots];
@@ -119,6 +119,7 @@ struct bspgemm_context {
     bool check = false;                 // BSPGEMM_CHECK: the exact flow never emits on unverified sizes
     int rw_blk = -1;                    // BSPGEMM_RW_BLK: 0 never / 1 always use the blocked extents table (default: per operand)
     int small = -1;                     // BSPGEMM_SMALL / BSPGEMM_OPT_SMALL_PATH: -1 automatic, 0 never, 1 whenever the product fits
+    bool bucket = false;                // BSPGEMM_BUCKET / BSPGEMM_OPT_BUCKET_PATH: numeric kernels try the bucket accumulator first
     bool debug_alloc = false;           // BSPGEMM_DEBUG_ALLOC: allocation trace on stderr
     bool dropin_timing = false;         // BSPGEMM_DROPIN_TIMING: stage times of the int32 drop-ins on stderr
 };

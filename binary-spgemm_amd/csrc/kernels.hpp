@@ -133,7 +133,8 @@ constexpr unsigned kErrCapacity = 1u;     // a row gathered more products than i
 constexpr unsigned kErrStaleTable = 2u;   // an operand's derived tables do not match its row_ptr (bspgemm_matrix_invalidate)
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
-                      int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false);
+                      int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false,
+                      bool bucket_path = false);   // bucket_path: numeric instances try the bucket accumulator first (wave_rows.inc)
 // debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] (either may be NULL) against row_ptr; sets kErrStaleTable in *err
 void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s);
 

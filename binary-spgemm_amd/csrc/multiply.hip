@@ -119,6 +119,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     slot.class_streams = ctx->class_streams;
     slot.small = false;
     slot.checked = ctx->check;
+    slot.bucket = ctx->bucket;
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
@@ -233,7 +234,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
-                                 C->d_col_idx, nullptr, ctx->d_err, sx);
+                                 C->d_col_idx, nullptr, ctx->d_err, sx, false, ctx->bucket);
             else
                 launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
@@ -286,6 +287,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     slot.class_streams = ctx->class_streams;
     slot.small = false;
     slot.checked = ctx->check;
+    slot.bucket = ctx->bucket;
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
@@ -349,7 +351,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
-                                 ctx->tmp, ctx->cnt, ctx->d_err, sx);
+                                 ctx->tmp, ctx->cnt, ctx->d_err, sx, false, ctx->bucket);
             else if (!Fm)
                 HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
