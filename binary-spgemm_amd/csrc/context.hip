@@ -98,9 +98,11 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     ctx->own_stream = true;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_prep), sizeof(PrepScalars)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), sizeof(SmallScalars)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_err), 64));
     HIPCHK(hipMemset(ctx->d_err, 0, 64));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_count), kNumBins * sizeof(int)));
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) HIPCHK(hipEventCreate(&e));
         for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) HIPCHK(hipEventCreate(&e));
@@ -136,9 +138,11 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
     hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
     hipFree(ctx->hub_rec); hipFree(ctx->hub_pre);
+    hipFree(ctx->fb_rec); hipFree(ctx->fb_pre); hipFree(ctx->fb_count);
     if (ctx->h) hipHostFree(ctx->h);
     hipFree(ctx->d_prep);
     hipFree(ctx->d_err);
+    hipFree(ctx->d_small);
     hipFree(ctx->chunk_row);
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) if (e) hipEventDestroy(e);
@@ -259,7 +263,8 @@ bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     if (rows <= ctx->rows_cap) return BSPGEMM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_tiles);
-    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask); hipFree(ctx->hpartials); hipFree(ctx->fb_rec); hipFree(ctx->fb_pre);
+    ctx->fb_rec = nullptr; ctx->fb_pre = nullptr;
     ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = ctx->Fmask = ctx->hpartials = nullptr;
     ctx->cnt = ctx->bin_tiles = nullptr;
     ctx->rec = nullptr;
@@ -275,6 +280,8 @@ bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_rec), cap * sizeof(RowRec)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_pre), cap * sizeof(long long)));
     if (!ctx->hub_rec) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_rec), kHeavySortMax * sizeof(RowRec)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_pre), kHeavySortMax * sizeof(long long)));

@@ -58,6 +58,7 @@ struct HostScalars {
     long long heavy_total;              // entries the heavy rows may need in the workspace
     PrepScalars prep;                   // upper-bound flow: the prepass results, fetched in one copy
     unsigned err;                       // ctx->d_err, read back when BSPGEMM_OPT_CHECK is on
+    bsp::SmallScalars small;            // small path: its one read-back
 };
 
 struct bspgemm_context {
@@ -92,6 +93,9 @@ struct bspgemm_context {
     size_t rows_cap = 0;
     long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr, *Fmask = nullptr;
     long long *hpartials = nullptr;     // per scan tile: workspace entries of its heavy rows (scanned)
+    RowRec *fb_rec = nullptr;           // bucket path: records of the rows handed back to the rank-bitmap kernel, by class segment
+    long long *fb_pre = nullptr;        //   ... and their resolved output offsets
+    int *fb_count = nullptr;            //   ... and how many per class (kNumBins ints, zeroed per multiply)
     RowRec *hub_rec = nullptr;          // the hub rows' records by decreasing products (kHeavySortMax entries)
     long long *hub_pre = nullptr;
     int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
@@ -103,6 +107,7 @@ struct bspgemm_context {
     size_t tmp_cap = 0;
     int *tmp = nullptr;
     PrepScalars *d_prep = nullptr;      // device side of HostScalars::prep
+    bsp::SmallScalars *d_small = nullptr; // device side of HostScalars::small
     unsigned *d_err = nullptr;          // device error word of the accumulate kernels (kErrCapacity | kErrStaleTable)
     int *chunk_row = nullptr;           // compaction: row of every kCompactGran-th output (left by the count scan)
     size_t chunk_cap = 0;

@@ -134,7 +134,15 @@ constexpr unsigned kErrStaleTable = 2u;   // an operand's derived tables do not 
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
                       int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false,
-                      bool bucket_path = false);   // bucket_path: numeric instances try the bucket accumulator first (wave_rows.inc)
+                      const int *nrows_dev = nullptr);
+// nrows_dev != NULL: LIST MODE -- rec / recpre are a device-side list of *nrows_dev <= nrows records (rows the bucket kernel
+// handed back); the grid covers the list's capacity `nrows`, waves beyond its length leave at once
+// numeric phase, one wave per row, BUCKET accumulator (wave_bkt.hip): same arguments; rows it cannot take (fullest range
+// bucket above kBktMaxLoad) are appended to fb_rec / fb_pre (record, resolved output offset), *fb_count of them, for a
+// list-mode launch_wave_rows right behind it on the same stream
+void launch_wave_bkt(int bin, const int2 *ab, const int *Bcol, const RowRec *rec, const long long *recpre,
+                     const long long *row_ptr, int nrows, int row_begin, int *tmp, int *cnt,
+                     RowRec *fb_rec, long long *fb_pre, int *fb_count, unsigned *err, hipStream_t s);
 // debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] (either may be NULL) against row_ptr; sets kErrStaleTable in *err
 void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s);
 
@@ -170,6 +178,23 @@ void launch_mask_lengths(const long long *F, const int *Frow, int row_begin, int
 // product count) only sizes the grid.
 void launch_compact(const int *tmp, const long long *Fprefix, const long long *row_ptr,
                     int row_lo, int row_hi, long long max_out, int *col_idx, hipStream_t s, const int *chunk_row = nullptr);
+
+// ---- single-round-trip path for small products (small.hip) ----------------------------------------
+constexpr int kSmallMaxProducts = 65536;   // products (and entries of C.col_idx / the workspace) the path is sized for
+constexpr int kSmallMaxRow = 2048;         // products of one row (one wave sorts them in LDS)
+constexpr int kSmallMaxRows = 1 << 17;     // rows multiplied (one workgroup scans them)
+constexpr int kSmallMaxNnzA = 32768;       // A-nonzeros in the multiplied rows (host-side eligibility)
+struct SmallScalars {                      // what the host reads back, once, at the end
+    long long totalF;                      // products
+    long long nnzC;
+    int bail;                              // 1: the product does not fit this path (nothing was written): take the general flow
+    int nonempty;                          // rows with products
+    int a_lo, a_hi;                        // A.row_ptr at the ends of the row range
+};
+// list[] (ints, >= nrows), F / Fprefix (nrows + 1), cnt (nrows), tmp and col_idx (kSmallMaxProducts each), row_ptr (nrows + 1)
+void launch_small(const int *Arow, const int *Acol, const int *Brow, const int *Bcol, int row_begin, int nrows,
+                  long long *F, long long *Fprefix, int *list, int *cnt, int *tmp, long long *row_ptr, int *col_idx,
+                  SmallScalars *sc, hipStream_t s);
 
 // int64 row_ptr -> int32 (operand form of a product)
 void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);

@@ -59,6 +59,7 @@ static void hub_order(bspgemm_context *ctx, int b, int n, const RowRec *&rec, co
 // the prepass uses them; check_verdict (after the multiply's last synchronisation) turns a set bit into a failure
 static bspgemm_status check_arm(bspgemm_context *ctx, const bspgemm_matrix *B, hipStream_t s)
 {
+    if (ctx->bucket) HIPCHK(hipMemsetAsync(ctx->fb_count, 0, kNumBins * sizeof(int), s));   // the bucket kernels' hand-back lists
     if (!ctx->check) return BSPGEMM_OK;
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(unsigned), s));
     launch_check_tables(B->d_row_ptr, B->rows, B->d_deg8, B->blk8_state == 1 ? B->d_blk8 : nullptr, ctx->d_err, s);
@@ -70,6 +71,23 @@ static bspgemm_status check_verdict(bspgemm_context *ctx)
     if (ctx->h->err & kErrStaleTable)
         return FAIL(BSPGEMM_ERR_INVALID, "operand B was rewritten in place: its derived tables do not match its row_ptr (call bspgemm_matrix_invalidate)");
     return FAIL(BSPGEMM_ERR_INVALID, "a row gathered more products than its capacity class holds (operand changed during the multiply?)");
+}
+
+// numeric launch of one one-wave class: the rank-bitmap kernel, or (BSPGEMM_OPT_BUCKET_PATH, cols > 8192) the bucket kernel
+// with the rank-bitmap kernel in list mode right behind it for the rows it handed back.  `seg` = the class's segment start
+// in rec[] (the hand-back list uses the same segments).
+static void launch_one_wave_class(bspgemm_context *ctx, int b, int levels, const bspgemm_matrix *B, const RowRec *rec,
+                                  const long long *recpre, const long long *row_ptr, int n, int row_begin, int *dst, int *cnt,
+                                  size_t seg, hipStream_t sx)
+{
+    if (ctx->bucket && levels >= 2) {
+        launch_wave_bkt(b, ctx->ab, B->d_col_idx, rec, recpre, row_ptr, n, row_begin, dst, cnt, ctx->fb_rec + seg, ctx->fb_pre + seg,
+                        ctx->fb_count + b, ctx->d_err, sx);
+        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, ctx->fb_rec + seg, ctx->fb_pre + seg, nullptr, n, row_begin,
+                         dst, cnt, ctx->d_err, sx, false, ctx->fb_count + b);
+    } else {
+        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, row_ptr, n, row_begin, dst, cnt, ctx->d_err, sx);
+    }
 }
 
 // closes the multiply's stat slot (its events have all completed: the caller has synchronised)
@@ -233,8 +251,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
-                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
-                                 C->d_col_idx, nullptr, ctx->d_err, sx, false, ctx->bucket);
+                launch_one_wave_class(ctx, b, levels, B, rec, recpre, C->d_row_ptr, n, row_begin, C->d_col_idx, nullptr, bin_start[b], sx);
             else
                 launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
@@ -350,8 +367,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
-                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
-                                 ctx->tmp, ctx->cnt, ctx->d_err, sx, false, ctx->bucket);
+                launch_one_wave_class(ctx, b, levels, B, rec, recpre, nullptr, n, row_begin, ctx->tmp, ctx->cnt, bin_start[b], sx);
             else if (!Fm)
                 HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
@@ -395,6 +411,75 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     return BSPGEMM_OK;
 }
 
+// Small products (csrc/small.hip): five launches, no size goes to the host before the end, ONE read-back.  *bailed = true
+// (status OK, no result) when the device found that the product does not fit the path: the caller runs the general flow.
+static bool small_eligible(const bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B, int R)
+{
+    if (ctx->small == 0 || R <= 0 || R > kSmallMaxRows || A->nnz > kSmallMaxNnzA) return false;
+    if (ctx->small == 1) return true;
+    // automatic: expected products = A's nonzeros x B's mean row length must leave room below the path's capacity
+    const double mean_b = B->rows > 0 ? (double)B->nnz / (double)B->rows : 0.0;
+    return (double)A->nnz * mean_b <= 0.5 * kSmallMaxProducts;
+}
+
+static bspgemm_status multiply_small(bspgemm_context *ctx, const bspgemm_matrix *A, const bspgemm_matrix *B,
+                                     int row_begin, int row_end, bspgemm_result **out, bool *bailed)
+{
+    *bailed = false;
+    if (!out) return FAIL(BSPGEMM_ERR_INVALID, "result pointer is NULL");
+    *out = nullptr;
+    if (bspgemm_status st = check_operands(ctx, A, B, row_begin, row_end)) return st;
+    if (bspgemm_status st = use_device(ctx)) return st;
+    const int R = row_end - row_begin;
+    hipStream_t s = ctx->stream;
+    if (bspgemm_status st = ensure_rows(ctx, (size_t)R + 1)) return st;
+    if (bspgemm_status st = ensure_tmp(ctx, (size_t)kSmallMaxProducts + 1)) return st;
+    bspgemm_result *C = new (std::nothrow) bspgemm_result{ctx, R, 0, nullptr, nullptr, 0};
+    if (!C) return FAIL(BSPGEMM_ERR_ALLOC, "result");
+    auto bail = [&](bspgemm_status st) {
+        hipStreamSynchronize(s);
+        bspgemm_result_free(C);
+        return st;
+    };
+    ctx->slot_head = (ctx->slot_head + 1) % bspgemm_context::kStatSlots;
+    bspgemm_context::StatSlot &slot = ctx->slots[ctx->slot_head];
+    slot.used = false;
+    slot.flow = BSPGEMM_FLOW_UPPER_BOUND;                  // (rows are placed by their product count and squeezed together)
+    slot.class_streams = 1;
+    slot.small = true;
+    slot.checked = false;
+    slot.bucket = false;
+    slot.prepass_kernel = 2;
+    HIPCHK_B(hipEventRecord(slot.ev[0], s));
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
+    HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(kSmallMaxProducts)));
+    C->col_cap = kSmallMaxProducts;
+    launch_small(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, row_begin, R, ctx->F, ctx->Fprefix,
+                 reinterpret_cast<int *>(ctx->rec), ctx->cnt, ctx->tmp, C->d_row_ptr, C->d_col_idx, ctx->d_small, s);
+    HIPCHK_B(hipGetLastError());
+    HostScalars *h = ctx->h;
+    HIPCHK_B(hipMemcpyAsync(&h->small, ctx->d_small, sizeof(SmallScalars), hipMemcpyDeviceToHost, s));
+    for (int e = 1; e <= 4; e++) HIPCHK_B(hipEventRecord(slot.ev[e], s));   // one phase: everything is "total"
+    HIPCHK_B(hipStreamSynchronize(s));
+    if (h->small.bail) {
+        bspgemm_result_free(C);
+        *bailed = true;
+        return BSPGEMM_OK;
+    }
+    C->nnz = h->small.nnzC;
+    h->totalF = h->small.totalF;
+    h->nnzC = h->small.nnzC;
+    h->a_lo = h->small.a_lo;
+    h->a_hi = h->small.a_hi;
+    memset(h->bin_count, 0, sizeof h->bin_count);
+    h->bin_count[0] = R - h->small.nonempty;               // (one "class": every non-empty row is sorted by one wave)
+    h->bin_count[kWaveBins] = h->small.nonempty;
+    int cls_n[2][kNumBins] = {};
+    close_slot(ctx, R, h, h->small.totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols));
+    *out = C;
+    return BSPGEMM_OK;
+}
+
 extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_matrix *A,
                                            const bspgemm_matrix *B, int row_begin, int row_end,
                                            bspgemm_result **out)
@@ -406,6 +491,11 @@ extern "C" bspgemm_status bspgemm_multiply(bspgemm_context *ctx, const bspgemm_m
     // pass costs most of a numeric pass), but it holds 2F entries.  Default: upper-bound, and exact
     // when that does not fit.
     if (!ctx) return FAIL(BSPGEMM_ERR_INVALID, "ctx is NULL");
+    if (A && B && ctx->flow != BSPGEMM_FLOW_EXACT && small_eligible(ctx, A, B, row_end - row_begin)) {
+        bool bailed = false;
+        const bspgemm_status st = multiply_small(ctx, A, B, row_begin, row_end, out, &bailed);
+        if (st != BSPGEMM_OK || !bailed) return st;        // done (or failed); a product that did not fit falls through
+    }
     if (ctx->flow == BSPGEMM_FLOW_EXACT) return multiply_exact(ctx, A, B, row_begin, row_end, out);
     bspgemm_status st = multiply_upper_bound(ctx, A, B, nullptr, row_begin, row_end, out);
     if (st == BSPGEMM_ERR_ALLOC && ctx->flow == BSPGEMM_FLOW_AUTO) {
