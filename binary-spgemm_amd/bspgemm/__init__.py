@@ -65,7 +65,7 @@ class BspgemmError(RuntimeError):
 
 MAX_BINS = 20      # BSPGEMM_MAX_BINS
 FLOWS = {"auto": 0, "upper-bound": 1, "exact": 2}                                    # BSPGEMM_FLOW_*
-OPTIONS = {"class_streams": 1, "blocked_extents": 2, "check": 3, "small_path": 4, "bucket_path": 5}    # bspgemm_option
+OPTIONS = {"class_streams": 1, "blocked_extents": 2, "check": 3, "small_path": 4}    # bspgemm_option
 
 
 class Stats(C.Structure):
@@ -76,7 +76,7 @@ class Stats(C.Structure):
                 ("ms_bin", C.c_float * MAX_BINS), ("ms_bin_count", C.c_float * MAX_BINS),
                 ("t_bin", C.c_float * MAX_BINS), ("t_bin_count", C.c_float * MAX_BINS), ("bins", C.c_int),
                 ("bin_cap", C.c_int * MAX_BINS), ("flow", C.c_int), ("prepass_kernel", C.c_int),
-                ("class_streams", C.c_int), ("small_path", C.c_int), ("checked", C.c_int), ("bucket_path", C.c_int)]
+                ("class_streams", C.c_int), ("small_path", C.c_int), ("checked", C.c_int)]
 
     def as_dict(self):
         arrays = ("rows_per_bin", "ms_bin", "ms_bin_count", "t_bin", "t_bin_count", "bin_cap")

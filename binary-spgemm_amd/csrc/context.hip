@@ -102,7 +102,6 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_err), 64));
     HIPCHK(hipMemset(ctx->d_err, 0, 64));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_count), kNumBins * sizeof(int)));
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) HIPCHK(hipEventCreate(&e));
         for (auto &ph : sl.ev_cls) for (auto &c : ph) for (auto &e : c) HIPCHK(hipEventCreate(&e));
@@ -119,7 +118,6 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     ctx->check = getenv("BSPGEMM_CHECK") != nullptr;
     if (const char *e = getenv("BSPGEMM_RW_BLK")) ctx->rw_blk = atoi(e) ? 1 : 0;
     if (const char *e = getenv("BSPGEMM_SMALL")) ctx->small = atoi(e) ? 1 : 0;
-    if (const char *e = getenv("BSPGEMM_BUCKET")) ctx->bucket = atoi(e) != 0;
     ctx->debug_alloc = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
     ctx->dropin_timing = getenv("BSPGEMM_DROPIN_TIMING") != nullptr;
     if (ctx->debug_alloc)
@@ -138,7 +136,6 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->cnt); hipFree(ctx->bin_tiles); hipFree(ctx->bin_count); hipFree(ctx->tmp);
     hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->ab); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
     hipFree(ctx->hub_rec); hipFree(ctx->hub_pre);
-    hipFree(ctx->fb_rec); hipFree(ctx->fb_pre); hipFree(ctx->fb_count);
     if (ctx->h) hipHostFree(ctx->h);
     hipFree(ctx->d_prep);
     hipFree(ctx->d_err);
@@ -263,8 +260,7 @@ bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     if (rows <= ctx->rows_cap) return BSPGEMM_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     hipFree(ctx->F); hipFree(ctx->Fprefix); hipFree(ctx->partials); hipFree(ctx->cnt); hipFree(ctx->bin_tiles);
-    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask); hipFree(ctx->hpartials); hipFree(ctx->fb_rec); hipFree(ctx->fb_pre);
-    ctx->fb_rec = nullptr; ctx->fb_pre = nullptr;
+    hipFree(ctx->rec); hipFree(ctx->recpre); hipFree(ctx->Fmask); hipFree(ctx->hpartials);
     ctx->F = ctx->Fprefix = ctx->partials = ctx->recpre = ctx->Fmask = ctx->hpartials = nullptr;
     ctx->cnt = ctx->bin_tiles = nullptr;
     ctx->rec = nullptr;
@@ -280,8 +276,6 @@ bspgemm_status ensure_rows(bspgemm_context *ctx, size_t rows)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_tiles), (tiles + 1) * kNumBins * sizeof(int)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->rec), cap * sizeof(RowRec)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->recpre), cap * sizeof(long long)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_rec), cap * sizeof(RowRec)));
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->fb_pre), cap * sizeof(long long)));
     if (!ctx->hub_rec) {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_rec), kHeavySortMax * sizeof(RowRec)));
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->hub_pre), kHeavySortMax * sizeof(long long)));
@@ -429,7 +423,6 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     st.class_streams = sl.class_streams;
     st.small_path = sl.small ? 1 : 0;
     st.checked = sl.checked ? 1 : 0;
-    st.bucket_path = sl.bucket ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, sl.ev[0], sl.ev[4]);
     hipEventElapsedTime(&st.ms_prepass, sl.ev[0], sl.ev[1]);
     hipEventElapsedTime(&st.ms_count, sl.ev[1], sl.ev[2]);
@@ -473,9 +466,6 @@ extern "C" bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_optio
         if (value < -1 || value > 1) return FAIL(BSPGEMM_ERR_INVALID, "small path: -1, 0 or 1");
         ctx->small = value;
         return BSPGEMM_OK;
-    case BSPGEMM_OPT_BUCKET_PATH:
-        ctx->bucket = value != 0;
-        return BSPGEMM_OK;
     }
     return FAIL(BSPGEMM_ERR_INVALID, "unknown option");
 }
@@ -488,7 +478,6 @@ extern "C" int bspgemm_get_option(const bspgemm_context *ctx, bspgemm_option opt
     case BSPGEMM_OPT_BLOCKED_EXTENTS: return ctx->rw_blk;
     case BSPGEMM_OPT_CHECK: return ctx->check ? 1 : 0;
     case BSPGEMM_OPT_SMALL_PATH: return ctx->small;
-    case BSPGEMM_OPT_BUCKET_PATH: return ctx->bucket ? 1 : 0;
     }
     return INT_MIN;
 }

@@ -82,7 +82,7 @@ struct bspgemm_context {
         int cls_n[2][kNumBins] = {};
         bool used = false;
         int flow = 0, prepass_kernel = 0, class_streams = 0;   // which path ran (bspgemm_stats)
-        bool small = false, checked = false, bucket = false;
+        bool small = false, checked = false;
     };
     static constexpr int kStatSlots = 16;
     StatSlot slots[kStatSlots];
@@ -93,9 +93,6 @@ struct bspgemm_context {
     size_t rows_cap = 0;
     long long *F = nullptr, *Fprefix = nullptr, *partials = nullptr, *recpre = nullptr, *Fmask = nullptr;
     long long *hpartials = nullptr;     // per scan tile: workspace entries of its heavy rows (scanned)
-    RowRec *fb_rec = nullptr;           // bucket path: records of the rows handed back to the rank-bitmap kernel, by class segment
-    long long *fb_pre = nullptr;        //   ... and their resolved output offsets
-    int *fb_count = nullptr;            //   ... and how many per class (kNumBins ints, zeroed per multiply)
     RowRec *hub_rec = nullptr;          // the hub rows' records by decreasing products (kHeavySortMax entries)
     long long *hub_pre = nullptr;
     int *cnt = nullptr, *bin_tiles = nullptr, *bin_count = nullptr;
@@ -124,7 +121,6 @@ struct bspgemm_context {
     bool check = false;                 // BSPGEMM_CHECK: the exact flow never emits on unverified sizes
     int rw_blk = -1;                    // BSPGEMM_RW_BLK: 0 never / 1 always use the blocked extents table (default: per operand)
     int small = -1;                     // BSPGEMM_SMALL / BSPGEMM_OPT_SMALL_PATH: -1 automatic, 0 never, 1 whenever the product fits
-    bool bucket = false;                // BSPGEMM_BUCKET / BSPGEMM_OPT_BUCKET_PATH: numeric kernels try the bucket accumulator first
     bool debug_alloc = false;           // BSPGEMM_DEBUG_ALLOC: allocation trace on stderr
     bool dropin_timing = false;         // BSPGEMM_DROPIN_TIMING: stage times of the int32 drop-ins on stderr
 };

@@ -133,16 +133,7 @@ constexpr unsigned kErrCapacity = 1u;     // a row gathered more products than i
 constexpr unsigned kErrStaleTable = 2u;   // an operand's derived tables do not match its row_ptr (bspgemm_matrix_invalidate)
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
-                      int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false,
-                      const int *nrows_dev = nullptr);
-// nrows_dev != NULL: LIST MODE -- rec / recpre are a device-side list of *nrows_dev <= nrows records (rows the bucket kernel
-// handed back); the grid covers the list's capacity `nrows`, waves beyond its length leave at once
-// numeric phase, one wave per row, BUCKET accumulator (wave_bkt.hip): same arguments; rows it cannot take (fullest range
-// bucket above kBktMaxLoad) are appended to fb_rec / fb_pre (record, resolved output offset), *fb_count of them, for a
-// list-mode launch_wave_rows right behind it on the same stream
-void launch_wave_bkt(int bin, const int2 *ab, const int *Bcol, const RowRec *rec, const long long *recpre,
-                     const long long *row_ptr, int nrows, int row_begin, int *tmp, int *cnt,
-                     RowRec *fb_rec, long long *fb_pre, int *fb_count, unsigned *err, hipStream_t s);
+                      int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false);
 // debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] (either may be NULL) against row_ptr; sets kErrStaleTable in *err
 void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s);
 

@@ -59,7 +59,6 @@ static void hub_order(bspgemm_context *ctx, int b, int n, const RowRec *&rec, co
 // the prepass uses them; check_verdict (after the multiply's last synchronisation) turns a set bit into a failure
 static bspgemm_status check_arm(bspgemm_context *ctx, const bspgemm_matrix *B, hipStream_t s)
 {
-    if (ctx->bucket) HIPCHK(hipMemsetAsync(ctx->fb_count, 0, kNumBins * sizeof(int), s));   // the bucket kernels' hand-back lists
     if (!ctx->check) return BSPGEMM_OK;
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(unsigned), s));
     launch_check_tables(B->d_row_ptr, B->rows, B->d_deg8, B->blk8_state == 1 ? B->d_blk8 : nullptr, ctx->d_err, s);
@@ -71,23 +70,6 @@ static bspgemm_status check_verdict(bspgemm_context *ctx)
     if (ctx->h->err & kErrStaleTable)
         return FAIL(BSPGEMM_ERR_INVALID, "operand B was rewritten in place: its derived tables do not match its row_ptr (call bspgemm_matrix_invalidate)");
     return FAIL(BSPGEMM_ERR_INVALID, "a row gathered more products than its capacity class holds (operand changed during the multiply?)");
-}
-
-// numeric launch of one one-wave class: the rank-bitmap kernel, or (BSPGEMM_OPT_BUCKET_PATH, cols > 8192) the bucket kernel
-// with the rank-bitmap kernel in list mode right behind it for the rows it handed back.  `seg` = the class's segment start
-// in rec[] (the hand-back list uses the same segments).
-static void launch_one_wave_class(bspgemm_context *ctx, int b, int levels, const bspgemm_matrix *B, const RowRec *rec,
-                                  const long long *recpre, const long long *row_ptr, int n, int row_begin, int *dst, int *cnt,
-                                  size_t seg, hipStream_t sx)
-{
-    if (ctx->bucket && levels >= 2) {
-        launch_wave_bkt(b, ctx->ab, B->d_col_idx, rec, recpre, row_ptr, n, row_begin, dst, cnt, ctx->fb_rec + seg, ctx->fb_pre + seg,
-                        ctx->fb_count + b, ctx->d_err, sx);
-        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, ctx->fb_rec + seg, ctx->fb_pre + seg, nullptr, n, row_begin,
-                         dst, cnt, ctx->d_err, sx, false, ctx->fb_count + b);
-    } else {
-        launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, row_ptr, n, row_begin, dst, cnt, ctx->d_err, sx);
-    }
 }
 
 // closes the multiply's stat slot (its events have all completed: the caller has synchronised)
@@ -137,7 +119,6 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     slot.class_streams = ctx->class_streams;
     slot.small = false;
     slot.checked = ctx->check;
-    slot.bucket = ctx->bucket;
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
@@ -251,7 +232,8 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
-                launch_one_wave_class(ctx, b, levels, B, rec, recpre, C->d_row_ptr, n, row_begin, C->d_col_idx, nullptr, bin_start[b], sx);
+                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
+                                 C->d_col_idx, nullptr, ctx->d_err, sx);
             else
                 launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
@@ -304,7 +286,6 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     slot.class_streams = ctx->class_streams;
     slot.small = false;
     slot.checked = ctx->check;
-    slot.bucket = ctx->bucket;
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
@@ -367,7 +348,8 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
-                launch_one_wave_class(ctx, b, levels, B, rec, recpre, nullptr, n, row_begin, ctx->tmp, ctx->cnt, bin_start[b], sx);
+                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
+                                 ctx->tmp, ctx->cnt, ctx->d_err, sx);
             else if (!Fm)
                 HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
@@ -448,7 +430,6 @@ static bspgemm_status multiply_small(bspgemm_context *ctx, const bspgemm_matrix 
     slot.class_streams = 1;
     slot.small = true;
     slot.checked = false;
-    slot.bucket = false;
     slot.prepass_kernel = 2;
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));

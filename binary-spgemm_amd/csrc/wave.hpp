@@ -41,38 +41,6 @@ __device__ __forceinline__ int wave_incl_scan(int x)
     return x;
 }
 
-// wave-wide unsigned max / min, result broadcast to every lane (the scan's DPP steps as a reduction: after the
-// row shifts lane 15 of a row of 16 holds the row's value, the two broadcasts carry it into lane 63)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ u32 dpp_or_old(u32 old, u32 x)
-{
-    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ u32 wave_max_u32(u32 x)
-{
-    x = max(x, dpp_or_old<0x111, 0xF>(0u, x));
-    x = max(x, dpp_or_old<0x112, 0xF>(0u, x));
-    x = max(x, dpp_or_old<0x114, 0xF>(0u, x));
-    x = max(x, dpp_or_old<0x118, 0xF>(0u, x));
-    x = max(x, dpp_or_old<0x142, 0xA>(0u, x));
-    x = max(x, dpp_or_old<0x143, 0xC>(0u, x));
-    return (u32)__builtin_amdgcn_readlane((int)x, 63);
-}
-__device__ __forceinline__ u32 wave_min_u32(u32 x)
-{
-    x = min(x, dpp_or_old<0x111, 0xF>(~0u, x));
-    x = min(x, dpp_or_old<0x112, 0xF>(~0u, x));
-    x = min(x, dpp_or_old<0x114, 0xF>(~0u, x));
-    x = min(x, dpp_or_old<0x118, 0xF>(~0u, x));
-    x = min(x, dpp_or_old<0x142, 0xA>(~0u, x));
-    x = min(x, dpp_or_old<0x143, 0xC>(~0u, x));
-    return (u32)__builtin_amdgcn_readlane((int)x, 63);
-}
-// neighbours across the whole wave (GFX9 DPP wave shifts): lane l gets lane l+1's / lane l-1's value; the lane without a
-// neighbour (63 / 0) gets `old`
-__device__ __forceinline__ u32 wave_next(u32 old, u32 x) { return dpp_or_old<0x130, 0xF>(old, x); }   // wave_shl:1
-__device__ __forceinline__ u32 wave_prev(u32 old, u32 x) { return dpp_or_old<0x138, 0xF>(old, x); }   // wave_shr:1
-
 __device__ __forceinline__ int wave_bcast(int x, int lane)   // lane must be wave-uniform
 {
     return __builtin_amdgcn_readlane(x, lane);

@@ -2,5 +2,5 @@
 #include "wave_rows.inc"
 namespace bsp {
 template void launch_wave_levels<1>(int, const int2 *, const int *, int, const RowRec *, const long long *,
-                                    const long long *, int, int, int *, int *, unsigned *, hipStream_t, bool, const int *);
+                                    const long long *, int, int, int *, int *, unsigned *, hipStream_t, bool);
 }

@@ -66,7 +66,7 @@ const char *bspgemm_build_info(void);
  * per context after a multiply (10.7 GB for BASELINE config 3).  bspgemm_destroy releases all.
  * Environment (read once, in bspgemm_create; every knob also has a setter, bspgemm_set_option / _set_flow /
  * _set_class_timing, which is what a running program uses): BSPGEMM_FLOW=auto|upper-bound|exact,
- * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1, BSPGEMM_BUCKET=0|1,
+ * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1,
  * BSPGEMM_DEBUG_ALLOC, BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.          */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
@@ -144,17 +144,13 @@ bspgemm_status bspgemm_set_class_timing(bspgemm_context *ctx, int on);
  *                    kernels verify each row's gathered product count against its capacity class (a stale
  *                    derived table -- see bspgemm_matrix_invalidate -- then fails the multiply with
  *                    BSPGEMM_ERR_INVALID instead of overrunning LDS)
- *   BUCKET_PATH      0/1   the one-wave numeric kernels try the bucket accumulator first (csrc/wave_rows.inc, BKT): range
- *                    buckets + in-register odd-even passes instead of the three ranked bitmap sweeps; rows with clustered
- *                    columns fall back to the sweeps inside the same kernel
  *   SMALL_PATH       -1 automatic (default: products of at most 65536 with a cached result buffer take the
  *                    single-launch path), 0 never, 1 whenever the product fits it                       */
 typedef enum bspgemm_option {
     BSPGEMM_OPT_CLASS_STREAMS   = 1,
     BSPGEMM_OPT_BLOCKED_EXTENTS = 2,
     BSPGEMM_OPT_CHECK           = 3,
-    BSPGEMM_OPT_SMALL_PATH      = 4,
-    BSPGEMM_OPT_BUCKET_PATH     = 5
+    BSPGEMM_OPT_SMALL_PATH      = 4
 } bspgemm_option;
 bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_option opt, int value);
 /* current value of a knob (INT32_MIN for an unknown option or a NULL context) */
@@ -239,7 +235,6 @@ typedef struct bspgemm_stats {
     int     class_streams;   /* streams the class launches alternated over                           */
     int     small_path;      /* 1: the single-launch path for small products ran                      */
     int     checked;         /* 1: the device-side capacity guard was armed (BSPGEMM_OPT_CHECK)       */
-    int     bucket_path;     /* 1: the one-wave numeric kernels ran with the bucket accumulator enabled       */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
 /* ... and of earlier ones: age 0 = the last multiply, 1 = the one before, ... up to 15.  The

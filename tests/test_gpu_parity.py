@@ -326,38 +326,6 @@ def test_small_product_path(ctx):
         ctx.set_option("small_path", old)
 
 
-def test_bucket_accumulator_path(ctx):
-    """csrc/wave_bkt.hip (BSPGEMM_OPT_BUCKET_PATH): the one-wave numeric kernels with the bucket accumulator and the
-    rank-bitmap kernel in list mode behind them.  Inputs for both halves: uniform columns (every row stays on the bucket
-    path, duplicates or not), rows whose columns sit in a few narrow clusters or are mostly duplicates (fullest bucket
-    above the limit: handed back through the device-side list), every capacity class, a banded matrix (tiny column
-    range: shift 0), unsorted B rows with duplicates."""
-    old = ctx.get_option("bucket_path")
-    ctx.set_option("bucket_path", 1)
-    try:
-        for name in ("levels2_uniform_n2e16_d16", "levels2_rmat_s14_g500", "levels3_uniform_n300k", "banded", "dups_unsorted",
-                     "special_rows", "powerlaw_n2e15_d32"):
-            rp, ci, n = CASES[name]()
-            erp, eci = O.spgemm(rp, ci, rp, ci, n)
-            crp, cci, st = hip_product(ctx, rp, ci, n, rp, ci, n)
-            assert st["bucket_path"] == 1
-            assert_same(crp, cci, erp, eci)
-        # clustered columns: B rows live in 3 clusters of 40 columns each, far apart -> a row's products fill 3 buckets
-        rng = np.random.default_rng(951)
-        nb, ncols = 4000, 3_000_000
-        centres = np.array([1000, 1_500_000, 2_999_000])
-        b_rows = np.repeat(np.arange(nb), 12)
-        b_cols = centres[rng.integers(0, 3, size=b_rows.size)] + rng.integers(0, 40, size=b_rows.size)
-        b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, nb)
-        a_rp, a_ci = gen.uniform_rect(3000, nb, 25, seed=952)
-        erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
-        crp, cci, st = hip_product(ctx, a_rp, a_ci, nb, b_rp, b_ci, ncols)
-        assert st["bucket_path"] == 1
-        assert_same(crp, cci, erp, eci)
-    finally:
-        ctx.set_option("bucket_path", old)
-
-
 def test_class_timing_switch(ctx):
     """per-class event brackets are off by default (they cost ~1 % of a large product), on request the stats carry them;
     the result is the same either way and the phase times are always there"""
