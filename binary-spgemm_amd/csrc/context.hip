@@ -99,6 +99,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&ctx->h), sizeof(HostScalars), hipHostMallocDefault));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_prep), sizeof(PrepScalars)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), sizeof(SmallScalars)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_small_tiles), sizeof(SmallTiles)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->d_err), 64));
     HIPCHK(hipMemset(ctx->d_err, 0, 64));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&ctx->bin_count), kNumBins * sizeof(int)));
@@ -140,6 +141,7 @@ extern "C" void bspgemm_destroy(bspgemm_context *ctx)
     hipFree(ctx->d_prep);
     hipFree(ctx->d_err);
     hipFree(ctx->d_small);
+    hipFree(ctx->d_small_tiles);
     hipFree(ctx->chunk_row);
     for (auto &sl : ctx->slots) {
         for (auto &e : sl.ev) if (e) hipEventDestroy(e);

@@ -105,6 +105,7 @@ struct bspgemm_context {
     int *tmp = nullptr;
     PrepScalars *d_prep = nullptr;      // device side of HostScalars::prep
     bsp::SmallScalars *d_small = nullptr; // device side of HostScalars::small
+    bsp::SmallTiles *d_small_tiles = nullptr;   // scan scratch of the small path
     unsigned *d_err = nullptr;          // device error word of the accumulate kernels (kErrCapacity | kErrStaleTable)
     int *chunk_row = nullptr;           // compaction: row of every kCompactGran-th output (left by the count scan)
     size_t chunk_cap = 0;

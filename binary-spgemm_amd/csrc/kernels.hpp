@@ -182,10 +182,16 @@ struct SmallScalars {                      // what the host reads back, once, at
     int nonempty;                          // rows with products
     int a_lo, a_hi;                        // A.row_ptr at the ends of the row range
 };
+struct SmallTiles {                        // device scratch of the path's two scans (per 32 rows / per 256 rows)
+    long long f32[kSmallMaxRows / 32];     // products
+    int nz32[kSmallMaxRows / 32];          // non-empty rows
+    int mx32[kSmallMaxRows / 32];          // largest row
+    int c256[kSmallMaxRows / 256];         // outputs
+};
 // list[] (ints, >= nrows), F / Fprefix (nrows + 1), cnt (nrows), tmp and col_idx (kSmallMaxProducts each), row_ptr (nrows + 1)
 void launch_small(const int *Arow, const int *Acol, const int *Brow, const int *Bcol, int row_begin, int nrows,
                   long long *F, long long *Fprefix, int *list, int *cnt, int *tmp, long long *row_ptr, int *col_idx,
-                  SmallScalars *sc, hipStream_t s);
+                  SmallTiles *tl, SmallScalars *sc, hipStream_t s);
 
 // int64 row_ptr -> int32 (operand form of a product)
 void launch_narrow_row_ptr(const long long *src, int *dst, int n, hipStream_t s);

@@ -436,7 +436,7 @@ static bspgemm_status multiply_small(bspgemm_context *ctx, const bspgemm_matrix 
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_col_idx), result_bytes_colidx(kSmallMaxProducts)));
     C->col_cap = kSmallMaxProducts;
     launch_small(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_col_idx, row_begin, R, ctx->F, ctx->Fprefix,
-                 reinterpret_cast<int *>(ctx->rec), ctx->cnt, ctx->tmp, C->d_row_ptr, C->d_col_idx, ctx->d_small, s);
+                 reinterpret_cast<int *>(ctx->rec), ctx->cnt, ctx->tmp, C->d_row_ptr, C->d_col_idx, ctx->d_small_tiles, ctx->d_small, s);
     HIPCHK_B(hipGetLastError());
     HostScalars *h = ctx->h;
     HIPCHK_B(hipMemcpyAsync(&h->small, ctx->d_small, sizeof(SmallScalars), hipMemcpyDeviceToHost, s));

@@ -19,23 +19,31 @@ __global__ __launch_bounds__(256) void k(u32 *sink)
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < WORDS; i += 64) p[i] = i;
     __syncthreads();
-    u32 a = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+    // eight random words per lane, drawn once; per iteration they move by an odd step (two cheap VALU instructions per
+    // access: the first version of this test drew a fresh LCG value per access and measured v_mul_lo_u32, not the LDS)
+    u32 ra[UNROLL], acc = 0;
+    {
+        u32 a = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) { a = a * 1664525u + 1013904223u; ra[u] = a >> 12; }
+    }
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            a = a * 1664525u + 1013904223u;
-            const u32 r = (a >> 12) & (WORDS - 1);                       // random word
-            const u32 b = ((lane * STRIDE + u * 4) & (WORDS - 4));       // blocked: lane stride STRIDE words
+            const u32 r = (ra[u] + it * 67) & (WORDS - 1);               // random word
+            const u32 b = ((lane * STRIDE + u * 4 + it * 8) & (WORDS - 4));   // blocked: lane stride STRIDE words
+            const u32 a = r ^ it;
             if (KIND == 0) acc += p[r];                                  // ds_read_b32 random
             if (KIND == 1) p[r] = a;                                     // ds_write_b32 random
             if (KIND == 2) atomicOr(&p[r], a);                           // ds_or_b32 (no return) random
             if (KIND == 3) acc += atomicAdd(&p[r], 1u);                  // ds_add_rtn_u32 random
-            if (KIND == 4) acc += p[(lane + u * 64) & (WORDS - 1)];      // ds_read_b32 coalesced
+            if (KIND == 4) acc += p[(lane + u * 64 + it) & (WORDS - 1)]; // ds_read_b32 coalesced
             if (KIND == 5) { const v4 v = *reinterpret_cast<const v4 *>(p + b); acc += v.x + v.w; }   // ds_read_b128 blocked
             if (KIND == 6) { const v4 v = {a, a, a, a}; *reinterpret_cast<v4 *>(p + b) = v; }          // ds_write_b128 blocked
             if (KIND == 7) acc += p[r & 31];                             // ds_read_b32, 32 distinct words (few addresses: broadcast)
             if (KIND == 8) { acc += p[r]; acc += ((unsigned short *)p)[r * 2 + 1]; }   // b32 + u16 at the same index (rank + prefix)
             if (KIND == 9) acc += p[(r & ~63u) | (lane & 63)];           // random row, own bank: conflict-free "random"
+            if (KIND == 10) { const unsigned long long v = *reinterpret_cast<const unsigned long long *>(p + (r & ~1u)); acc += (u32)v + (u32)(v >> 32); }   // ds_read_b64 random
         }
     }
     if (acc == 0x12345678u) *sink = acc;
@@ -63,6 +71,7 @@ int main()
     run<9, 0>("ds_read_b32 random row, lane's own bank (no conflicts)", 1);
     run<0, 0>("ds_read_b32 random", 1);
     run<8, 0>("ds_read_b32 + ds_read_u16 random, same index", 2);
+    run<10, 0>("ds_read_b64 random (8-byte aligned)", 1);
     run<1, 0>("ds_write_b32 random", 1);
     run<2, 0>("ds_or_b32 random (no return)", 1);
     run<3, 0>("ds_add_rtn_u32 random", 1);

@@ -1,10 +1,11 @@
 """Wall time and phase split of the small BASELINE shapes (cfg1 validity fixture, cfg2 uniform n=2^18 d=16)."""
 import os, sys, time
-sys.path.insert(0, "binary-spgemm_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "binary-spgemm_amd"))
 import torch, bspgemm
 ctx = bspgemm.Context(0)
 cases = []
-rp, ci, m, n = bspgemm.readCOO(os.path.join("tests", "golden", "validity_test.mtx"))
+rp, ci, m, n = bspgemm.readCOO(os.path.join(ROOT, "tests", "golden", "validity_test.mtx"))
 cases.append(("cfg1 validity", rp, ci, n))
 rp, ci, n = bspgemm.gen_uniform(1 << 18, 16, seed=1)
 cases.append(("cfg2 uniform 2^18 d16", rp, ci, n))
