@@ -500,11 +500,21 @@ def main():
             if len(fam) == len(instances):
                 # FETCH_SIZE under-counts wide coalesced reads 2x on gfx950 (MI355X_MICROARCH.md, HBM): the
                 # gathers of this kernel are 4-byte accesses, so the raw figure is quoted, uncorrected
-                traffic = int(sum(k.get("fetch_bytes_corrected_high", 2 * k["fetch_bytes"]) + k["write_bytes"] for k in fam))
-                traffic_src = prof_path + (" (WRITE_SIZE + 2 x FETCH_SIZE of the %d instances: gfx950 tallies 128-byte read "
-                                           "requests at 64 bytes; the gathers' 64-byte requests make this the HIGH bound, "
-                                           "low bound %d)" % (len(fam), int(sum(k.get("fetch_bytes_corrected_low", k["fetch_bytes"])
-                                                                              + k["write_bytes"] for k in fam))))
+                if all("fetch_bytes_calibrated" in k for k in fam):
+                    # round 4: FETCH_SIZE calibrated on this access (profiles/r04_fetch_calibration_unaligned.txt) and applied to the
+                    # matrix's own row_ptr (tools/gather_traffic_model.py): a request is a 128-byte line's wanted 64-byte sectors,
+                    # tallied as 64 bytes -- the factor says what the gather of THIS matrix moves per byte FETCH_SIZE shows
+                    traffic = int(sum(k["fetch_bytes_calibrated"] + k["write_bytes"] for k in fam))
+                    traffic_src = prof_path + (" (WRITE_SIZE + FETCH_SIZE x %.3f of the %d instances: the counter calibrated on "
+                                               "64-80-byte rows at dword alignment and applied to this matrix's row_ptr; uncorrected "
+                                               "FETCH_SIZE + WRITE_SIZE = %d)" % (prof.get("gather_calibration_factor") or 0.0, len(fam),
+                                                                                  int(sum(k["fetch_bytes"] + k["write_bytes"] for k in fam))))
+                else:
+                    traffic = int(sum(k.get("fetch_bytes_corrected_high", 2 * k["fetch_bytes"]) + k["write_bytes"] for k in fam))
+                    traffic_src = prof_path + (" (WRITE_SIZE + 2 x FETCH_SIZE of the %d instances: gfx950 tallies 128-byte read "
+                                               "requests at 64 bytes; the gathers' 64-byte requests make this the HIGH bound, "
+                                               "low bound %d)" % (len(fam), int(sum(k.get("fetch_bytes_corrected_low", k["fetch_bytes"])
+                                                                                  + k["write_bytes"] for k in fam))))
         sym_bytes = int(4 * F_row[wave].sum() + 8 * a_row[wave].sum() + 4 * wave.sum())
         ms_cnt = phase_ms["ms_count"]
         flow = "exact" if float(np.sum(bin_count_ms)) > 0 else "upper-bound"
@@ -532,7 +542,7 @@ def main():
         roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
                     "traffic": None, "error": "%s: %s" % (type(e).__name__, e)}
     value = nnz_total * args.steps / elapsed / 1e9
-    step_traffic = prof.get("step_total_bytes") if prof else None
+    step_traffic = (prof.get("step_total_bytes_calibrated") or prof.get("step_total_bytes")) if prof else None
     out = {
         "metric": "output nnz/sec (GNZ/s)", "value": round(value, 4), "unit": "GNZ/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

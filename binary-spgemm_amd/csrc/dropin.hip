@@ -100,7 +100,15 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
     std::atomic<long long> pieces_ready{0};
     std::atomic<bool> early_failed{false}, early_stop{false}, early_set{false};
     std::thread prep;
-    if (bound >= 0 && bound <= INT_MAX) {
+    // The early destination is sized by the BOUND, which heavy merging can leave far above nnz(C): it is only used while it
+    // stays below half of the host memory that is free right now (and below INT_MAX entries); otherwise the result is
+    // malloc'ed with its true size after the multiply, as before.
+    bool early_fits = bound >= 0 && bound <= INT_MAX;
+    if (early_fits) {
+        const long pages = sysconf(_SC_AVPHYS_PAGES), psize = sysconf(_SC_PAGESIZE);
+        if (pages > 0 && psize > 0 && (double)bound * sizeof(int) > 0.5 * (double)pages * (double)psize) early_fits = false;
+    }
+    if (early_fits) {
         early_bytes = (size_t)(bound > 0 ? bound : 1) * sizeof(int);
         piece_pinned.assign((early_bytes + kPiece - 1) / kPiece, 0);
         const int dev = ctx->device;
@@ -152,15 +160,26 @@ static bspgemm_status dropin_run(const int *Acol, const int *Arow, int r0, int r
     auto download_early = [&](long long nnz, int64_t *rp64) -> bspgemm_status {
         const size_t need = (size_t)nnz * sizeof(int);
         hipStream_t s = ctx->stream;
-        HIPCHK(hipMemcpyAsync(rp64, C->d_row_ptr, ((size_t)rows + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
-        for (size_t k = 0, off = 0; off < need; k++, off += kPiece) {
-            while (pieces_ready.load(std::memory_order_acquire) <= (long long)k) usleep(50);
-            const size_t len = (need - off < kPiece) ? need - off : kPiece;
-            HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(early) + off, reinterpret_cast<const char *>(C->d_col_idx) + off, len,
-                                  hipMemcpyDeviceToHost, s));
-        }
+        // a copy that fails after others were queued must not leave a DMA writing into memory that is about to be
+        // unpinned and freed: every exit drains the stream first
+        auto run = [&]() -> bspgemm_status {
+            HIPCHK(hipMemcpyAsync(rp64, C->d_row_ptr, ((size_t)rows + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+            for (size_t k = 0, off = 0; off < need; k++, off += kPiece) {
+                while (pieces_ready.load(std::memory_order_acquire) <= (long long)k) {
+                    if (early_failed) return FAIL(BSPGEMM_ERR_ALLOC, "early destination");
+                    usleep(50);
+                }
+                const size_t len = (need - off < kPiece) ? need - off : kPiece;
+                HIPCHK(hipMemcpyAsync(reinterpret_cast<char *>(early) + off, reinterpret_cast<const char *>(C->d_col_idx) + off, len,
+                                      hipMemcpyDeviceToHost, s));
+            }
+            return BSPGEMM_OK;
+        };
+        const bspgemm_status st = run();
         early_stop = true;                                 // pieces beyond nnz(C) are not needed
-        HIPCHK(hipStreamSynchronize(s));
+        const hipError_t e = hipStreamSynchronize(s);
+        if (st) return st;
+        HIPCHK(e);
         return BSPGEMM_OK;
     };
     if (prep.joinable() && st) { early_stop = true; prep.join(); }
