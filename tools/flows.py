@@ -1,6 +1,6 @@
 """Times both multiply flows on one box: tools/flows.py [scale] (R-MAT mild, A*A)."""
-import sys, time
-sys.path.insert(0, "binary-spgemm_amd")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "binary-spgemm_amd"))
 import torch, bspgemm
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 ctx = bspgemm.Context(0)
