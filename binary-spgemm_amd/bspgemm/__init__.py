@@ -52,7 +52,7 @@ EXPORTS = [
     "bspgemm_readCOO_ex", "bspgemm_comm_create_host", "bspgemm_comm_rank", "bspgemm_comm_size",
     "bspgemm_comm_gather_col_idx", "SpGEMM_hip_multi", "bspgemm_device_count", "bspgemm_stats_at",
     "bspgemm_set_flow", "bspgemm_set_class_timing", "bspgemm_build_info", "bspgemm_matrix_invalidate", "bspgemm_comm_agree", "bspgemm_comm_inject_failure",
-    "bspgemm_set_option", "bspgemm_get_option", "bspgemm_matrix_uses_blocked_table",
+    "bspgemm_set_option", "bspgemm_get_option", "bspgemm_matrix_uses_blocked_table", "bspgemm_matrix_uses_padded_rows",
 ]
 
 
@@ -65,7 +65,7 @@ class BspgemmError(RuntimeError):
 
 MAX_BINS = 20      # BSPGEMM_MAX_BINS
 FLOWS = {"auto": 0, "upper-bound": 1, "exact": 2}                                    # BSPGEMM_FLOW_*
-OPTIONS = {"class_streams": 1, "blocked_extents": 2, "check": 3, "small_path": 4}    # bspgemm_option
+OPTIONS = {"class_streams": 1, "blocked_extents": 2, "check": 3, "small_path": 4, "padded_rows": 5}    # bspgemm_option
 
 
 class Stats(C.Structure):
@@ -76,7 +76,7 @@ class Stats(C.Structure):
                 ("ms_bin", C.c_float * MAX_BINS), ("ms_bin_count", C.c_float * MAX_BINS),
                 ("t_bin", C.c_float * MAX_BINS), ("t_bin_count", C.c_float * MAX_BINS), ("bins", C.c_int),
                 ("bin_cap", C.c_int * MAX_BINS), ("flow", C.c_int), ("prepass_kernel", C.c_int),
-                ("class_streams", C.c_int), ("small_path", C.c_int), ("checked", C.c_int)]
+                ("class_streams", C.c_int), ("small_path", C.c_int), ("checked", C.c_int), ("padded_rows", C.c_int)]
 
     def as_dict(self):
         arrays = ("rows_per_bin", "ms_bin", "ms_bin_count", "t_bin", "t_bin_count", "bin_cap")
@@ -156,6 +156,7 @@ def lib():
     L.bspgemm_set_option.argtypes = [VP, C.c_int, C.c_int]
     L.bspgemm_get_option.argtypes = [VP, C.c_int]
     L.bspgemm_matrix_uses_blocked_table.argtypes = [VP]
+    L.bspgemm_matrix_uses_padded_rows.argtypes = [VP]
     L.bspgemm_matrix_upload.argtypes = [VP, C.c_int, C.c_int, VP, VP, PVP]
     L.bspgemm_matrix_wrap_device.argtypes = [VP, C.c_int, C.c_int, C.c_int64, VP, VP, PVP]
     L.bspgemm_matrix_free.argtypes = [VP]
@@ -335,7 +336,7 @@ class Context:
         _chk(lib().bspgemm_set_flow(self._h, FLOWS[flow]), "set_flow")
 
     def set_option(self, name, value):
-        """bspgemm_set_option: "class_streams" 1..3, "blocked_extents" -1/0/1, "check" 0/1, "small_path" -1/0/1"""
+        """bspgemm_set_option: "class_streams" 1..3, "blocked_extents" -1/0/1, "check" 0/1, "small_path" -1/0/1, "padded_rows" -1/0/1"""
         _chk(lib().bspgemm_set_option(self._h, OPTIONS[name], int(value)), "set_option(%s)" % name)
 
     def get_option(self, name):
@@ -424,6 +425,11 @@ class Matrix:
     def uses_blocked_table(self):
         """1 / 0 once the operand has been used as B (which prepass kernel it gets), -1 before"""
         return lib().bspgemm_matrix_uses_blocked_table(self._h)
+
+    @property
+    def uses_padded_rows(self):
+        """1 / 0 once the operand has been used as B (whether its rows are gathered from the padded copy), -1 before"""
+        return lib().bspgemm_matrix_uses_padded_rows(self._h)
 
     def free(self):
         if self._h:

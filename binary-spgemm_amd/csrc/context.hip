@@ -38,6 +38,59 @@ bspgemm_status ensure_deg8(const bspgemm_matrix *m)
     return BSPGEMM_OK;
 }
 
+// The padded copy of B.col_idx (rows on 64-byte boundaries).  OPT-IN (BSPGEMM_OPT_PADDED_ROWS, default off): it cuts the
+// bytes the gather moves by 22 % on the bench matrix (9.4 -> 7.3 GB, tools/gather_traffic_model.py) and the numeric phase by
+// nothing there (3.336 -> 3.327 / 3.314 ms, profiles/r04_ab_padded_rows.log); with rows of exactly 16 entries (uniform
+// matrices: every row is one aligned sector) it is worth 8-9 % of the numeric phase (profiles/r04_alignment_probe.log).
+// Value -1 decides per operand: at least 2^20 nonzeros, a mean row length of 8 or more, the padded copy at most twice the
+// original and below 2^31 entries.
+bspgemm_status ensure_pad(const bspgemm_matrix *m)
+{
+    if (m->pad_state) return BSPGEMM_OK;
+    m->pad_state = 2;
+    bspgemm_context *ctx = m->ctx;
+    const int force = ctx->pad_rows;
+    if (force == 0 || m->rows <= 0 || m->nnz <= 0) return BSPGEMM_OK;
+    if (force < 0 && (m->nnz < (1ll << 20) || m->nnz < 8ll * m->rows)) return BSPGEMM_OK;
+    hipStream_t s = ctx->stream;
+    const size_t rows = (size_t)m->rows;
+    int *plen = nullptr;
+    long long *pp64 = nullptr, *partials = nullptr;
+    auto drop = [&] { hipFree(plen); hipFree(pp64); hipFree(partials); };
+    auto bail = [&](bspgemm_status st) {
+        hipStreamSynchronize(s);
+        drop();
+        hipFree(m->d_col_pad); hipFree(m->d_row_ptr_pad); hipFree(m->d_ext);
+        m->d_col_pad = nullptr; m->d_row_ptr_pad = nullptr; m->d_ext = nullptr;
+        return st;
+    };
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&plen), rows * sizeof(int)));
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&pp64), (rows + 1) * sizeof(long long)));
+    HIPCHK_B(hipMalloc(reinterpret_cast<void **>(&partials), (rows / 2048 + 4) * sizeof(long long)));
+    launch_pad_lengths(m->d_row_ptr, m->rows, plen, s);
+    launch_scan_counts(plen, m->rows, pp64, partials, nullptr, s);
+    long long total = 0;
+    HIPCHK_B(hipMemcpyAsync(&total, pp64 + rows, sizeof(long long), hipMemcpyDeviceToHost, s));
+    HIPCHK_B(hipStreamSynchronize(s));
+    if (total > 0x7fffffffll - 64 || (force < 0 && total > 2 * m->nnz)) { drop(); return BSPGEMM_OK; }   // (stays "not for this operand")
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_col_pad), ((size_t)total + 64) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_row_ptr_pad), (rows + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_ext), rows * sizeof(int2));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (force == 1) { snprintf(g_err, sizeof g_err, "padded copy of col_idx: %s", hipGetErrorString(e)); return bail(BSPGEMM_ERR_ALLOC); }
+        (void)bail(BSPGEMM_OK);                                // optional: an operand that does not fit twice is simply not padded
+        return BSPGEMM_OK;
+    }
+    launch_narrow_row_ptr(pp64, m->d_row_ptr_pad, m->rows + 1, s);
+    launch_pad_copy(m->d_row_ptr, m->d_col_idx, m->d_row_ptr_pad, m->rows, m->d_col_pad, m->d_ext, s);
+    HIPCHK_B(hipGetLastError());
+    HIPCHK_B(hipStreamSynchronize(s));
+    drop();
+    m->pad_state = 1;
+    return BSPGEMM_OK;
+}
+
 // Whether products with `m` as B go through the blocked table.  It pays when B.row_ptr is several
 // times an XCD's 4 MB L2 (R-MAT scale 22: 16.8 MB, k_row_work 1.20 -> 0.92 ms) and the operand is not
 // dominated by rows of 255+ nonzeros, whose lengths the table clamps (power-law n = 2^20: B.row_ptr
@@ -53,7 +106,7 @@ bspgemm_status ensure_blk8(const bspgemm_matrix *m)
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&m->d_blk8), (ints + 4) * sizeof(int)));
     unsigned long long *d_clamped = reinterpret_cast<unsigned long long *>(m->d_blk8 + ((ints + 1) & ~(size_t)1));
     HIPCHK(hipMemsetAsync(d_clamped, 0, sizeof(unsigned long long), m->ctx->stream));
-    launch_blk8(m->d_row_ptr, m->rows, m->d_blk8, d_clamped, m->ctx->stream);
+    launch_blk8(m->d_row_ptr, m->pad_state == 1 ? m->d_row_ptr_pad : nullptr, m->rows, m->d_blk8, d_clamped, m->ctx->stream);
     HIPCHK(hipGetLastError());
     unsigned long long clamped = 0;
     HIPCHK(hipMemcpyAsync(&clamped, d_clamped, sizeof(clamped), hipMemcpyDeviceToHost, m->ctx->stream));
@@ -119,6 +172,7 @@ extern "C" bspgemm_status bspgemm_create(int device, bspgemm_context **out)
     ctx->check = getenv("BSPGEMM_CHECK") != nullptr;
     if (const char *e = getenv("BSPGEMM_RW_BLK")) ctx->rw_blk = atoi(e) ? 1 : 0;
     if (const char *e = getenv("BSPGEMM_SMALL")) ctx->small = atoi(e) ? 1 : 0;
+    if (const char *e = getenv("BSPGEMM_PAD_ROWS")) { const int v = atoi(e); ctx->pad_rows = v < 0 ? -1 : (v ? 1 : 0); }
     ctx->debug_alloc = getenv("BSPGEMM_DEBUG_ALLOC") != nullptr;
     ctx->dropin_timing = getenv("BSPGEMM_DROPIN_TIMING") != nullptr;
     if (ctx->debug_alloc)
@@ -231,6 +285,9 @@ extern "C" void bspgemm_matrix_free(bspgemm_matrix *m)
     }
     hipFree(m->d_deg8);
     hipFree(m->d_blk8);
+    hipFree(m->d_col_pad);
+    hipFree(m->d_row_ptr_pad);
+    hipFree(m->d_ext);
     delete m;
 }
 extern "C" bspgemm_status bspgemm_matrix_invalidate(bspgemm_matrix *m)
@@ -240,9 +297,16 @@ extern "C" bspgemm_status bspgemm_matrix_invalidate(bspgemm_matrix *m)
     HIPCHK(hipStreamSynchronize(m->ctx->stream));          // a multiply may still be reading the tables
     hipFree(m->d_deg8);
     hipFree(m->d_blk8);
+    hipFree(m->d_col_pad);
+    hipFree(m->d_row_ptr_pad);
+    hipFree(m->d_ext);
     m->d_deg8 = nullptr;
     m->d_blk8 = nullptr;
     m->blk8_state = 0;
+    m->d_col_pad = nullptr;
+    m->d_row_ptr_pad = nullptr;
+    m->d_ext = nullptr;
+    m->pad_state = 0;
     return BSPGEMM_OK;
 }
 
@@ -425,6 +489,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     st.class_streams = sl.class_streams;
     st.small_path = sl.small ? 1 : 0;
     st.checked = sl.checked ? 1 : 0;
+    st.padded_rows = sl.padded ? 1 : 0;
     hipEventElapsedTime(&st.ms_total, sl.ev[0], sl.ev[4]);
     hipEventElapsedTime(&st.ms_prepass, sl.ev[0], sl.ev[1]);
     hipEventElapsedTime(&st.ms_count, sl.ev[1], sl.ev[2]);
@@ -468,6 +533,10 @@ extern "C" bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_optio
         if (value < -1 || value > 1) return FAIL(BSPGEMM_ERR_INVALID, "small path: -1, 0 or 1");
         ctx->small = value;
         return BSPGEMM_OK;
+    case BSPGEMM_OPT_PADDED_ROWS:
+        if (value < -1 || value > 1) return FAIL(BSPGEMM_ERR_INVALID, "padded rows: -1, 0 or 1");
+        ctx->pad_rows = value;
+        return BSPGEMM_OK;
     }
     return FAIL(BSPGEMM_ERR_INVALID, "unknown option");
 }
@@ -480,8 +549,15 @@ extern "C" int bspgemm_get_option(const bspgemm_context *ctx, bspgemm_option opt
     case BSPGEMM_OPT_BLOCKED_EXTENTS: return ctx->rw_blk;
     case BSPGEMM_OPT_CHECK: return ctx->check ? 1 : 0;
     case BSPGEMM_OPT_SMALL_PATH: return ctx->small;
+    case BSPGEMM_OPT_PADDED_ROWS: return ctx->pad_rows;
     }
     return INT_MIN;
+}
+
+extern "C" int bspgemm_matrix_uses_padded_rows(const bspgemm_matrix *m)
+{
+    if (!m || m->pad_state == 0) return -1;
+    return m->pad_state == 1 ? 1 : 0;
 }
 
 extern "C" int bspgemm_matrix_uses_blocked_table(const bspgemm_matrix *m)

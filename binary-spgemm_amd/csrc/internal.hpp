@@ -82,7 +82,7 @@ struct bspgemm_context {
         int cls_n[2][kNumBins] = {};
         bool used = false;
         int flow = 0, prepass_kernel = 0, class_streams = 0;   // which path ran (bspgemm_stats)
-        bool small = false, checked = false;
+        bool small = false, checked = false, padded = false;
     };
     static constexpr int kStatSlots = 16;
     StatSlot slots[kStatSlots];
@@ -121,6 +121,7 @@ struct bspgemm_context {
     int class_streams = 2;              // BSPGEMM_CLASS_STREAMS: streams the class launches alternate over (measured: 2 -8 %, 3 no better)
     bool check = false;                 // BSPGEMM_CHECK: the exact flow never emits on unverified sizes
     int rw_blk = -1;                    // BSPGEMM_RW_BLK: 0 never / 1 always use the blocked extents table (default: per operand)
+    int pad_rows = 0;                   // BSPGEMM_PAD_ROWS / BSPGEMM_OPT_PADDED_ROWS: 0 never (default), 1 always, -1 per operand: gather from a padded copy of B.col_idx
     int small = -1;                     // BSPGEMM_SMALL / BSPGEMM_OPT_SMALL_PATH: -1 automatic, 0 never, 1 whenever the product fits
     bool debug_alloc = false;           // BSPGEMM_DEBUG_ALLOC: allocation trace on stderr
     bool dropin_timing = false;         // BSPGEMM_DROPIN_TIMING: stage times of the int32 drop-ins on stderr
@@ -144,10 +145,19 @@ struct bspgemm_matrix {
     // A-nonzero instead of a B.row_ptr pair (csrc/prepass.hip: k_row_work_blk); built on first use as B
     mutable int *d_blk8 = nullptr;
     mutable int blk8_state = 0;          // 0 undecided, 1 in use, 2 not worth it for this operand
+    // padded copy of col_idx: every row on a 64-byte boundary (padded to a multiple of 16 entries), so that a gathered B row
+    // touches ceil(len / 16) 64-byte sectors instead of one more; built on first use as B (ensure_pad) when it pays
+    mutable int *d_col_pad = nullptr;
+    mutable int *d_row_ptr_pad = nullptr;  // rows + 1: where row j starts in d_col_pad
+    mutable int2 *d_ext = nullptr;         // {start in d_col_pad, length} per row: gathered by k_row_work when there is no blocked table
+    mutable int pad_state = 0;             // 0 undecided, 1 in use, 2 not for this operand
+    // what the accumulate kernels gather from: the padded copy when it exists
+    const int *gather_col() const { return pad_state == 1 ? d_col_pad : d_col_idx; }
 };
 
 bspgemm_status ensure_deg8(const bspgemm_matrix *m);
 bspgemm_status ensure_blk8(const bspgemm_matrix *m);
+bspgemm_status ensure_pad(const bspgemm_matrix *m);   // before ensure_blk8: the blocked table carries padded bases
 
 struct bspgemm_result {
     bspgemm_context *ctx;

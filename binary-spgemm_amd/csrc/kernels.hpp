@@ -73,21 +73,26 @@ struct RowRec {
 };
 
 // F_i = sum_{j in A_i} |B_j| for rows [row_begin,row_end)  ->  F[i-row_begin];
-// ab[jj] = (B.row_ptr[A.col_idx[jj]], |B_j|) for every A-nonzero of those rows
-// Bblk8 (may be null: gathers B.row_ptr pairs instead) = B's blocked extents table (launch_blk8)
-void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8,
+// ab[jj] = (start of B row A.col_idx[jj], |B_j|) for every A-nonzero of those rows.  What is gathered per A-nonzero:
+//   Bblk8 != NULL   B's blocked extents table (launch_blk8); with Bpad (the padded row_ptr) its bases and the starts are
+//                   positions in the PADDED copy of B.col_idx
+//   else Bext       the per-row table {start in the padded copy, length}
+//   else            a B.row_ptr pair (starts in B.col_idx itself)
+void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8, const int *Bpad, const int2 *Bext,
                      int row_begin, int row_end, long long *F, int2 *ab, hipStream_t s);
-// blk[3b..3b+2] = {row_ptr[8b], lengths of rows 8b..8b+7 clamped to 255, one byte each}
+// blk[3b..3b+2] = {start_ptr[8b] (NULL: row_ptr), lengths of rows 8b..8b+7 clamped to 255, one byte each}
 // *clamped_nnz (device, zeroed by the caller) += nonzeros in rows of 255 or more
-void launch_blk8(const int *row_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s);
+void launch_blk8(const int *row_ptr, const int *start_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s);
+// padded copy of an operand's col_idx (rows on 64-byte boundaries): plen[j] = ceil(len_j / 16) * 16; then, with pad_ptr =
+// its exclusive scan, the rows copied to col_pad and (ext != NULL) ext[j] = {pad_ptr[j], len_j}
+void launch_pad_lengths(const int *row_ptr, int n, int *plen, hipStream_t s);
+void launch_pad_copy(const int *row_ptr, const int *col_idx, const int *pad_ptr, int n, int *col_pad, int2 *ext, hipStream_t s);
 
 // deg8[i] = min(|row i|, 255): the per-operand byte table behind launch_row_products
 void launch_deg8(const int *row_ptr, int n, unsigned char *deg8, hipStream_t s);
 // F only (no extents), through B's byte table of row lengths
 void launch_row_products(const int *Arow, const int *Acol, const int *Brow, const unsigned char *Bdeg8,
                          int row_begin, int row_end, long long *F, hipStream_t s);
-// extents of the listed rows' A-nonzeros (heavy rows of a plain product)
-void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const int *Brow, int2 *ab, hipStream_t s);
 
 // exclusive scan of F (int64) into prefix[0..n] and, fused, classification of every row into
 // the capacity classes: rec[] holds the non-empty rows grouped by class (class b starts at
@@ -134,8 +139,9 @@ constexpr unsigned kErrStaleTable = 2u;   // an operand's derived tables do not 
 void launch_wave_rows(int bin, int levels, const int2 *ab, const int *Bcol, int cols,
                       const RowRec *rec, const long long *recpre, const long long *row_ptr, int nrows,
                       int row_begin, int *tmp, int *cnt, unsigned *err, hipStream_t s, bool count_only = false);
-// debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] (either may be NULL) against row_ptr; sets kErrStaleTable in *err
-void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s);
+// debug check (BSPGEMM_OPT_CHECK): deg8[] / blk8[] / the padded row_ptr (each may be NULL) against row_ptr; sets kErrStaleTable in *err
+void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, const int *pad_ptr, unsigned *err,
+                         hipStream_t s);
 
 // heavy rows: workspace -> final place (one workgroup per heavy row)
 void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recpre, int nrows,

@@ -61,7 +61,8 @@ static bspgemm_status check_arm(bspgemm_context *ctx, const bspgemm_matrix *B, h
 {
     if (!ctx->check) return BSPGEMM_OK;
     HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(unsigned), s));
-    launch_check_tables(B->d_row_ptr, B->rows, B->d_deg8, B->blk8_state == 1 ? B->d_blk8 : nullptr, ctx->d_err, s);
+    launch_check_tables(B->d_row_ptr, B->rows, B->d_deg8, B->blk8_state == 1 ? B->d_blk8 : nullptr,
+                        B->pad_state == 1 ? B->d_row_ptr_pad : nullptr, ctx->d_err, s);
     return BSPGEMM_OK;
 }
 static bspgemm_status check_verdict(bspgemm_context *ctx)
@@ -127,10 +128,14 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     const int scan_tiles = (R + 2047) / 2048;
     const int heavy_cols = B->cols > 0 ? B->cols : 1;
     // the extents ab[] come from the prepass, as in the other flow: both passes of the one-wave classes read them
+    if (bspgemm_status st = ensure_pad(B)) return bail(st);        // (first use as B: the padded copy, then the blocked table over it)
     if (bspgemm_status st = ensure_blk8(B)) return bail(st);       // (wrapped device arrays: first use)
     if (bspgemm_status st = check_arm(ctx, B, s)) return bail(st);
     slot.prepass_kernel = B->blk8_state == 1 ? 1 : 0;
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr, row_begin, row_end,
+    slot.padded = B->pad_state == 1;
+    const int *Bcol = B->gather_col();                     // B.col_idx, or its padded copy (the extents in ab[] point into it)
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr,
+                    B->pad_state == 1 ? B->d_row_ptr_pad : nullptr, B->pad_state == 1 ? B->d_ext : nullptr, row_begin, row_end,
                     ctx->F, ctx->ab, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
@@ -181,12 +186,12 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             if (b <= kWaveBins) {
                 // the numeric kernel without its emit half: |C_i| = F_i as soon as every product is seen to sit alone
                 // in its 32-column slot, the level-0 masks are only built and counted for the other rows
-                launch_wave_rows(b, wave_levels_for_cols(B->cols), ctx->ab, B->d_col_idx, B->cols, rec, nullptr, nullptr, n,
+                launch_wave_rows(b, wave_levels_for_cols(B->cols), ctx->ab, Bcol, B->cols, rec, nullptr, nullptr, n,
                                  row_begin, nullptr, ctx->cnt, ctx->d_err, sx, true);
             } else {
                 const long long *hpre = ctx->recpre + bin_start[b];
                 hub_order(ctx, b, n, rec, hpre, sx);
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, hpre, n,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
@@ -232,7 +237,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
-                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
+                launch_wave_rows(b, levels, ctx->ab, Bcol, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
                                  C->d_col_idx, nullptr, ctx->d_err, sx);
             else
                 launch_place_heavy(ctx->tmp, rec, recpre, n, C->d_row_ptr, row_begin, C->d_col_idx, sx);
@@ -289,10 +294,14 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
 
     HIPCHK_B(hipEventRecord(slot.ev[0], s));
     HIPCHK_B(result_alloc(ctx, reinterpret_cast<void **>(&C->d_row_ptr), result_bytes_rowptr(R)));
+    if (bspgemm_status st = ensure_pad(B)) return bail(st);
     if (bspgemm_status st = ensure_blk8(B)) return bail(st);
     if (bspgemm_status st = check_arm(ctx, B, s)) return bail(st);
     slot.prepass_kernel = B->blk8_state == 1 ? 1 : 0;
-    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr, row_begin, row_end,
+    slot.padded = B->pad_state == 1;
+    const int *Bcol = B->gather_col();                     // B.col_idx, or its padded copy (the extents in ab[] point into it)
+    launch_row_work(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->blk8_state == 1 ? B->d_blk8 : nullptr,
+                    B->pad_state == 1 ? B->d_row_ptr_pad : nullptr, B->pad_state == 1 ? B->d_ext : nullptr, row_begin, row_end,
                     ctx->F, ctx->ab, s);
     HostScalars *h = ctx->h;
     h->products = 0;
@@ -348,16 +357,16 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (!Fm) hub_order(ctx, b, n, rec, recpre, sx);
             if (!Fm && b <= kWaveBins)
-                launch_wave_rows(b, levels, ctx->ab, B->d_col_idx, B->cols, rec, recpre, nullptr, n, row_begin,
+                launch_wave_rows(b, levels, ctx->ab, Bcol, B->cols, rec, recpre, nullptr, n, row_begin,
                                  ctx->tmp, ctx->cnt, ctx->d_err, sx);
             else if (!Fm)
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin, ctx->tmp,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
             else if (b <= kWaveBins && wave_masked_supported(B->cols))
-                launch_wave_masked(b, ctx->ab, B->d_col_idx, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
+                launch_wave_masked(b, ctx->ab, Bcol, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
                                    row_begin, ctx->tmp, ctx->cnt, sx);
             else
-                HIPCHK_B(launch_dense_rows_masked(ctx->ab, B->d_col_idx, B->cols, rec, recpre, n, row_begin,
+                HIPCHK_B(launch_dense_rows_masked(ctx->ab, Bcol, B->cols, rec, recpre, n, row_begin,
                                                   ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
         }

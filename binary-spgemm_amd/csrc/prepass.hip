@@ -55,9 +55,14 @@ __device__ __forceinline__ long long rows_of_a_wave(int a0, int a1, int sub, Swe
 // ---------------------------------------------------------------------------------------
 // 8 lanes per A row: lanes stride the row's col_idx (coalesced 32-B pieces), gather the
 // B.row_ptr pair of every nonzero, reduce over the 8 lanes.
+// PAD: B's rows live in the padded copy of B.col_idx (every row on a 64-byte boundary, bspgemm_matrix::d_col_pad); what is
+// gathered per A-nonzero is then the row's entry {start in the padded copy, length} of the extents table Bext -- one aligned
+// 8-byte read, like the B.row_ptr pair it replaces.
+template <bool PAD>
 __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
                                                   const int *__restrict__ Acol,
                                                   const int *__restrict__ Brow,
+                                                  const int2 *__restrict__ Bext,
                                                   int row_begin, int nrows,
                                                   long long *__restrict__ F,
                                                   int2 *__restrict__ ab)
@@ -80,7 +85,10 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 pr[u].x = pr[u].y = 0;
-                if (j[u] >= 0) pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);   // one 8-B gather (dword aligned)
+                if (j[u] >= 0) {
+                    if (PAD) { const int2 e = Bext[j[u]]; pr[u].x = e.x; pr[u].y = e.x + e.y; }
+                    else pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);           // one 8-B gather (dword aligned)
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -106,8 +114,8 @@ __global__ __launch_bounds__(256) void k_row_work(const int *__restrict__ Arow,
 // in B.row_ptr itself (rows of 255+ nonzeros: rare).
 struct __attribute__((packed, aligned(4))) Blk8 { int base; unsigned lo, hi; };   // 12 B, only dword aligned
 
-__global__ __launch_bounds__(256) void k_blk8(const int *__restrict__ row_ptr, int n, int *__restrict__ blk,
-                                              unsigned long long *__restrict__ clamped_nnz)
+__global__ __launch_bounds__(256) void k_blk8(const int *__restrict__ row_ptr, const int *__restrict__ start_ptr, int n,
+                                              int *__restrict__ blk, unsigned long long *__restrict__ clamped_nnz)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b * 8 >= n) return;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void k_blk8(const int *__restrict__ row_ptr, i
     unsigned lo = 0u, hi = 0u;
     long long clamped = 0;
     int prev = row_ptr[r0];
-    const int base = prev;
+    const int base = start_ptr[r0];                                // where the block's first row starts (B.col_idx or its padded copy)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         int d = 0;
@@ -134,17 +142,22 @@ __global__ __launch_bounds__(256) void k_blk8(const int *__restrict__ row_ptr, i
     blk[3 * b + 1] = (int)lo;
     blk[3 * b + 2] = (int)hi;
 }
-void launch_blk8(const int *row_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s)
+void launch_blk8(const int *row_ptr, const int *start_ptr, int n, int *blk, unsigned long long *clamped_nnz, hipStream_t s)
 {
     if (n <= 0) return;
     const int nb = (n + 7) / 8;
-    hipLaunchKernelGGL(k_blk8, dim3((nb + 255) / 256), dim3(256), 0, s, row_ptr, n, blk, clamped_nnz);
+    hipLaunchKernelGGL(k_blk8, dim3((nb + 255) / 256), dim3(256), 0, s, row_ptr, start_ptr ? start_ptr : row_ptr, n, blk, clamped_nnz);
 }
 
+// PAD: the table's `base` is the block's first row in the PADDED copy of B.col_idx and a row starts behind the padded
+// lengths below it -- ceil(len / 16) * 16, summed over the bytes in SWAR form; rows behind a clamped byte are looked up in
+// the padded row_ptr (Bpad) and B.row_ptr.
+template <bool PAD>
 __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Arow,
                                                       const int *__restrict__ Acol,
                                                       const int *__restrict__ Brow,
                                                       const int *__restrict__ Bblk,
+                                                      const int *__restrict__ Bpad,
                                                       int row_begin, int nrows,
                                                       long long *__restrict__ F,
                                                       int2 *__restrict__ ab)
@@ -177,22 +190,35 @@ __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Ar
                 const u64 upto = (k == 7) ? d : (d & ((1ull << (8 * k + 8)) - 1ull));
                 const u64 v = ~upto;                                // a 255 byte at or below the row -> a zero byte here
                 sat[u] = j[u] >= 0 && ((v - 0x0101010101010101ull) & ~v & 0x8080808080808080ull) != 0ull;
-                start[u] = w[u].base + (int)__builtin_amdgcn_sad_u8((unsigned)below, 0u, 0u)
-                           + (int)__builtin_amdgcn_sad_u8((unsigned)(below >> 32), 0u, 0u);
+                if (PAD) {
+                    // sixteenths of each length below the row, rounded up: (len >> 4) + ((len & 15) != 0), byte by byte
+                    const u64 m0f = 0x0f0f0f0f0f0f0f0full, m01 = 0x0101010101010101ull;
+                    const u64 units = ((below >> 4) & m0f) + ((((below & m0f) + m0f) >> 4) & m01);
+                    start[u] = w[u].base + 16 * ((int)__builtin_amdgcn_sad_u8((unsigned)units, 0u, 0u)
+                                                 + (int)__builtin_amdgcn_sad_u8((unsigned)(units >> 32), 0u, 0u));
+                } else {
+                    start[u] = w[u].base + (int)__builtin_amdgcn_sad_u8((unsigned)below, 0u, 0u)
+                               + (int)__builtin_amdgcn_sad_u8((unsigned)(below >> 32), 0u, 0u);
+                }
                 len[u] = (int)((d >> (8 * k)) & 255ull);
             }
             // clamped lengths (B rows of 255+ nonzeros -- the hubs of a skewed graph, so these reads hit
             // L2): the exact pairs, again issued together
             Int2U pr[U];
+            int ps[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 pr[u].x = pr[u].y = 0;
-                if (sat[u]) pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);
+                ps[u] = 0;
+                if (sat[u]) {
+                    pr[u] = *reinterpret_cast<const Int2U *>(Brow + j[u]);
+                    if (PAD) ps[u] = Bpad[j[u]];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (j[u] >= 0) {
-                    if (sat[u]) { start[u] = pr[u].x; len[u] = pr[u].y - pr[u].x; }
+                    if (sat[u]) { start[u] = PAD ? ps[u] : pr[u].x; len[u] = pr[u].y - pr[u].x; }
                     ab[jj + stride * u] = make_int2(start[u], len[u]);
                     sum += (long long)len[u];
                 }
@@ -203,17 +229,57 @@ __global__ __launch_bounds__(256) void k_row_work_blk(const int *__restrict__ Ar
     if (r < nrows && sub == 0) F[r] = sum;
 }
 
-void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8,
+void launch_row_work(const int *Arow, const int *Acol, const int *Brow, const int *Bblk8, const int *Bpad, const int2 *Bext,
                      int row_begin, int row_end, long long *F, int2 *ab, hipStream_t s)
 {
     const int nrows = row_end - row_begin;
     if (nrows <= 0) return;
     const long long threads = (long long)nrows * 8;
     const int grid = (int)((threads + 255) / 256);
-    if (Bblk8)
-        hipLaunchKernelGGL(k_row_work_blk, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, Bblk8, row_begin, nrows, F, ab);
+    if (Bblk8 && Bpad)
+        hipLaunchKernelGGL(k_row_work_blk<true>, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, Bblk8, Bpad, row_begin, nrows, F, ab);
+    else if (Bblk8)
+        hipLaunchKernelGGL(k_row_work_blk<false>, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, Bblk8, nullptr, row_begin, nrows, F, ab);
+    else if (Bext)
+        hipLaunchKernelGGL(k_row_work<true>, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, Bext, row_begin, nrows, F, ab);
     else
-        hipLaunchKernelGGL(k_row_work, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, row_begin, nrows, F, ab);
+        hipLaunchKernelGGL(k_row_work<false>, dim3(grid), dim3(256), 0, s, Arow, Acol, Brow, nullptr, row_begin, nrows, F, ab);
+}
+
+// ---------------------------------------------------------------------------------------
+// The padded copy of an operand's col_idx: row j moves to pad_ptr[j], a multiple of 16 entries = a 64-byte boundary.
+// A B row read by the accumulate kernels then touches ceil(len / 16) 64-byte sectors instead of one more (the gather of the
+// bench matrix moves 7.3 GB instead of 9.4 GB: tools/gather_traffic_model.py).  plen[j] = padded length, scanned by
+// launch_scan_counts into pad_ptr64; narrowed to int32 once the total is known to fit.
+__global__ __launch_bounds__(256) void k_pad_lengths(const int *__restrict__ row_ptr, int n, int *__restrict__ plen)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) plen[i] = ((row_ptr[i + 1] - row_ptr[i]) + 15) & ~15;
+}
+void launch_pad_lengths(const int *row_ptr, int n, int *plen, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pad_lengths, dim3((n + 255) / 256), dim3(256), 0, s, row_ptr, n, plen);
+}
+// 16 lanes per row: entries copied, the pad slots of the row's last sector filled with its last column (never read as
+// products -- a lane past the end of a row is masked by its product index -- but defined); ext[j] = {pad_ptr[j], len}
+__global__ __launch_bounds__(256) void k_pad_copy(const int *__restrict__ row_ptr, const int *__restrict__ col_idx,
+                                                  const int *__restrict__ pad_ptr, int n, int *__restrict__ col_pad,
+                                                  int2 *__restrict__ ext)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(gid >> 4), sub = (int)(gid & 15);
+    if (r >= n) return;
+    const int s0 = row_ptr[r], len = row_ptr[r + 1] - s0, d0 = pad_ptr[r];
+    const int plen = (len + 15) & ~15;
+    for (int t = sub; t < plen; t += 16) col_pad[d0 + t] = col_idx[s0 + (t < len ? t : len - 1)];
+    if (sub == 0 && ext) ext[r] = make_int2(d0, len);
+}
+void launch_pad_copy(const int *row_ptr, const int *col_idx, const int *pad_ptr, int n, int *col_pad, int2 *ext, hipStream_t s)
+{
+    if (n <= 0) return;
+    const long long threads = (long long)n * 16;
+    hipLaunchKernelGGL(k_pad_copy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, row_ptr, col_idx, pad_ptr, n, col_pad, ext);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -273,7 +339,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ Ar
 // wrapped operand in place without bspgemm_matrix_invalidate would otherwise size rows from old lengths.
 __global__ __launch_bounds__(256) void k_check_tables(const int *__restrict__ row_ptr, int n,
                                                       const unsigned char *__restrict__ deg8, const int *__restrict__ blk,
-                                                      unsigned *__restrict__ err)
+                                                      const int *__restrict__ pad_ptr, unsigned *__restrict__ err)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -284,14 +350,16 @@ __global__ __launch_bounds__(256) void k_check_tables(const int *__restrict__ ro
     if (blk) {
         const int b = i >> 3, k = i & 7;
         const unsigned w = (unsigned)blk[3 * b + 1 + (k >> 2)];
-        bad = bad || ((w >> (8 * (k & 3))) & 255u) != want || (k == 0 && blk[3 * b] != row_ptr[i]);
+        bad = bad || ((w >> (8 * (k & 3))) & 255u) != want || (k == 0 && blk[3 * b] != (pad_ptr ? pad_ptr[i] : row_ptr[i]));
     }
+    if (pad_ptr) bad = bad || pad_ptr[i + 1] - pad_ptr[i] != ((d + 15) & ~15);
     if (bad) atomicOr(err, kErrStaleTable);
 }
-void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, unsigned *err, hipStream_t s)
+void launch_check_tables(const int *row_ptr, int rows, const unsigned char *deg8, const int *blk8, const int *pad_ptr, unsigned *err,
+                         hipStream_t s)
 {
-    if (rows <= 0 || (!deg8 && !blk8)) return;
-    hipLaunchKernelGGL(k_check_tables, dim3((rows + 255) / 256), dim3(256), 0, s, row_ptr, rows, deg8, blk8, err);
+    if (rows <= 0 || (!deg8 && !blk8 && !pad_ptr)) return;
+    hipLaunchKernelGGL(k_check_tables, dim3((rows + 255) / 256), dim3(256), 0, s, row_ptr, rows, deg8, blk8, pad_ptr, err);
 }
 
 void launch_row_products(const int *Arow, const int *Acol, const int *Brow, const unsigned char *Bdeg8,
@@ -302,25 +370,6 @@ void launch_row_products(const int *Arow, const int *Acol, const int *Brow, cons
     const long long threads = (long long)nrows * 8;
     hipLaunchKernelGGL(k_row_products, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, Arow, Acol, Brow, Bdeg8,
                        row_begin, nrows, F);
-}
-
-// ab[jj] = (B.row_ptr[A.col_idx[jj]], |B_j|) for the A-nonzeros of the listed rows only (the heavy
-// rows of a plain product: their kernel wants the extents like everybody else, but no count kernel
-// has passed over them).  One workgroup per row.
-__global__ __launch_bounds__(256) void k_extents_of_rows(const RowRec *__restrict__ rec, const int *__restrict__ Acol,
-                                                         const int *__restrict__ Brow, int2 *__restrict__ ab)
-{
-    const RowRec q = rec[blockIdx.x];
-    for (int t = threadIdx.x; t < q.alen; t += 256) {
-        const int j = Acol[q.a0 + t];
-        const int b0 = Brow[j];
-        ab[q.a0 + t] = make_int2(b0, Brow[j + 1] - b0);
-    }
-}
-void launch_extents_of_rows(const RowRec *rec, int nrows, const int *Acol, const int *Brow, int2 *ab, hipStream_t s)
-{
-    if (nrows <= 0) return;
-    hipLaunchKernelGGL(k_extents_of_rows, dim3(nrows), dim3(256), 0, s, rec, Acol, Brow, ab);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -66,7 +66,7 @@ const char *bspgemm_build_info(void);
  * per context after a multiply (10.7 GB for BASELINE config 3).  bspgemm_destroy releases all.
  * Environment (read once, in bspgemm_create; every knob also has a setter, bspgemm_set_option / _set_flow /
  * _set_class_timing, which is what a running program uses): BSPGEMM_FLOW=auto|upper-bound|exact,
- * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1,
+ * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1, BSPGEMM_PAD_ROWS=0|1,
  * BSPGEMM_DEBUG_ALLOC, BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.          */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
@@ -86,8 +86,9 @@ bspgemm_status bspgemm_matrix_upload(bspgemm_context *ctx, int rows, int cols,
                                      const int *row_ptr, const int *col_idx,
                                      bspgemm_matrix **out);
 /* Adopt device arrays the caller owns (not freed by bspgemm_matrix_free), row_ptr[0] == 0.
- * An operand is IMMUTABLE while the handle lives: the library keeps tables derived from row_ptr
- * (row lengths by the byte, blocked extents) and builds them on first use.  A caller that rewrites
+ * An operand is IMMUTABLE while the handle lives: the library keeps tables derived from row_ptr and col_idx
+ * (row lengths by the byte, blocked extents, a copy of col_idx with every row on a 64-byte boundary) and builds them
+ * on first use.  A caller that rewrites
  * the wrapped arrays in place must call bspgemm_matrix_invalidate before the next multiply; a
  * stale table would size rows from old lengths.                                                */
 bspgemm_status bspgemm_matrix_wrap_device(bspgemm_context *ctx, int rows, int cols, int64_t nnz,
@@ -144,13 +145,20 @@ bspgemm_status bspgemm_set_class_timing(bspgemm_context *ctx, int on);
  *                    kernels verify each row's gathered product count against its capacity class (a stale
  *                    derived table -- see bspgemm_matrix_invalidate -- then fails the multiply with
  *                    BSPGEMM_ERR_INVALID instead of overrunning LDS)
+ *   PADDED_ROWS      0 never (default), 1 always, -1 decide per operand (B of 2^20 nonzeros or more with a mean row length
+ *                    of 8 or more): the accumulate kernels gather B's rows from a derived copy of B.col_idx in which every
+ *                    row starts on a 64-byte boundary (a row then costs ceil(len / 16) 64-byte sectors instead of one
+ *                    more; +1.4 x nnz(B) ints of device memory on the bench matrix).  Opt-in: measured worth 8-9 % of the
+ *                    numeric phase on matrices whose rows all have 16 entries and nothing on the R-MAT bench matrix
+ *                    (DESIGN.md 4.2).  Decided on first use as B, like BLOCKED_EXTENTS.
  *   SMALL_PATH       -1 automatic (default: products of at most 65536 with a cached result buffer take the
  *                    single-launch path), 0 never, 1 whenever the product fits it                       */
 typedef enum bspgemm_option {
     BSPGEMM_OPT_CLASS_STREAMS   = 1,
     BSPGEMM_OPT_BLOCKED_EXTENTS = 2,
     BSPGEMM_OPT_CHECK           = 3,
-    BSPGEMM_OPT_SMALL_PATH      = 4
+    BSPGEMM_OPT_SMALL_PATH      = 4,
+    BSPGEMM_OPT_PADDED_ROWS     = 5
 } bspgemm_option;
 bspgemm_status bspgemm_set_option(bspgemm_context *ctx, bspgemm_option opt, int value);
 /* current value of a knob (INT32_MIN for an unknown option or a NULL context) */
@@ -158,6 +166,8 @@ int            bspgemm_get_option(const bspgemm_context *ctx, bspgemm_option opt
 /* 1 if products with `m` as B gather its blocked extents table, 0 if they gather B.row_ptr pairs, -1 if
  * that has not been decided yet (the operand has not been used as B since it was created / invalidated) */
 int            bspgemm_matrix_uses_blocked_table(const bspgemm_matrix *m);
+/* the same for the padded copy of col_idx (BSPGEMM_OPT_PADDED_ROWS) */
+int            bspgemm_matrix_uses_padded_rows(const bspgemm_matrix *m);
 
 /* C = F .* (A*B), complement convention of SpGEMM_masked (final/SpGEMM_mpi_omp.c:232-288):
  * a column k is admitted to row i only if (i,k) is in F's pattern.                           */
@@ -235,6 +245,7 @@ typedef struct bspgemm_stats {
     int     class_streams;   /* streams the class launches alternated over                           */
     int     small_path;      /* 1: the single-launch path for small products ran                      */
     int     checked;         /* 1: the device-side capacity guard was armed (BSPGEMM_OPT_CHECK)       */
+    int     padded_rows;     /* 1: B's rows were gathered from the padded copy of B.col_idx           */
 } bspgemm_stats;
 bspgemm_status bspgemm_last_stats(const bspgemm_context *ctx, bspgemm_stats *out);
 /* ... and of earlier ones: age 0 = the last multiply, 1 = the one before, ... up to 15.  The

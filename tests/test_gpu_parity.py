@@ -431,6 +431,68 @@ def test_blocked_extents_table_at_its_real_size(ctx):
     assert int((deg[sub_ci] >= 255).sum()) > 1000
 
 
+def test_padded_rows_forced(ctx):
+    """BSPGEMM_OPT_PADDED_ROWS: the accumulate kernels gather B's rows from a derived copy of B.col_idx in which every row
+    starts on a 64-byte boundary (csrc/context.hip ensure_pad, csrc/prepass.hip k_pad_copy); chosen per operand only for
+    large B, forced here -- with and without the blocked extents table (the two prepass kernels that produce padded
+    starts) -- on shapes with empty rows, rows of 1, 15, 16, 17 and 255+ entries, unsorted rows with duplicates,
+    A != B, an interior row range, heavy rows and the masked product.  bspgemm_stats.padded_rows says that it ran."""
+    rng = np.random.default_rng(961)
+    lens = rng.integers(0, 40, size=1500)
+    for r, L in ((0, 16), (1, 15), (2, 17), (3, 1), (4, 0), (5, 255), (6, 256), (7, 700), (8, 32), (9, 33), (1499, 48)):
+        lens[r] = L
+    ncols = 20000
+    b_rows = np.repeat(np.arange(1500), lens)
+    b_rp, b_ci = gen._csr_from_pairs(b_rows, rng.integers(0, ncols, size=b_rows.size), 1500, dedup=False, sort=False)
+    a_rows = np.concatenate([np.repeat(np.arange(900), rng.integers(0, 25, size=900)), np.full(400, 77), np.full(1400, 78)])
+    a_cols = rng.integers(0, 1500, size=a_rows.size)
+    a_cols[:16] = np.arange(16) % 10
+    a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, 900)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+    srp, sci, sn = gen.rmat(14, 16, (0.57, 0.19, 0.19, 0.05), 962)        # square, skewed: every class incl. heavy rows
+    prp, pci = O.spgemm(srp, sci, srp, sci, sn)
+    mrp0, mci0 = O.spgemm_masked(srp, sci, srp, sci, sn, srp, sci)
+    old_pad, old_blk = ctx.get_option("padded_rows"), ctx.get_option("blocked_extents")
+    try:
+        for blk in (0, 1):
+            ctx.set_option("blocked_extents", blk)
+            ctx.set_option("padded_rows", 1)
+            A = ctx.upload(a_rp, a_ci, 1500)
+            B = ctx.upload(b_rp, b_ci, ncols)
+            assert B.uses_padded_rows == -1
+            C = ctx.multiply(A, B)
+            st = ctx.stats()
+            assert st["padded_rows"] == 1 and B.uses_padded_rows == 1 and st["prepass_kernel"] == blk
+            crp, cci = C.download()
+            assert_same(crp, cci, erp, eci)
+            for h in (C, A, B):
+                h.free()
+            S = ctx.upload(srp, sci, sn)
+            C = ctx.multiply(S, S, 1000, 15000)
+            assert ctx.stats()["padded_rows"] == 1
+            grp, gci = C.download()
+            assert np.array_equal(grp, prp[1000:15001] - prp[1000]) and np.array_equal(gci, pci[prp[1000]:prp[15000]])
+            M = ctx.multiply_masked(S, S, S)
+            assert ctx.stats()["padded_rows"] == 1
+            mrp, mci = M.download()
+            assert_same(mrp, mci, mrp0, mci0)
+            for h in (C, M, S):
+                h.free()
+        # switched off: the same operands through B.col_idx itself
+        ctx.set_option("padded_rows", 0)
+        A = ctx.upload(a_rp, a_ci, 1500)
+        B = ctx.upload(b_rp, b_ci, ncols)
+        C = ctx.multiply(A, B)
+        assert ctx.stats()["padded_rows"] == 0 and B.uses_padded_rows == 0
+        crp, cci = C.download()
+        assert_same(crp, cci, erp, eci)
+        for h in (C, A, B):
+            h.free()
+    finally:
+        ctx.set_option("padded_rows", old_pad)
+        ctx.set_option("blocked_extents", old_blk)
+
+
 def test_rewritten_operand_needs_invalidate(ctx):
     """bspgemm_matrix_wrap_device: the library keeps tables derived from row_ptr (byte lengths, blocked extents).  A
     caller that rewrites the wrapped arrays in place and calls bspgemm_matrix_invalidate gets the new product; one
@@ -445,8 +507,9 @@ def test_rewritten_operand_needs_invalidate(ctx):
     d_rp = torch.from_numpy(np.asarray(rp1, np.int32)).to(dev)
     d_ci = torch.zeros(cap, dtype=torch.int32, device=dev)
     d_ci[: ci1.size] = torch.from_numpy(np.asarray(ci1, np.int32)).to(dev)
-    old_blk, old_chk = ctx.get_option("blocked_extents"), ctx.get_option("check")
-    ctx.set_option("blocked_extents", 1)                  # both derived tables in play
+    old_blk, old_chk, old_pad = ctx.get_option("blocked_extents"), ctx.get_option("check"), ctx.get_option("padded_rows")
+    ctx.set_option("blocked_extents", 1)                  # every derived table in play: byte lengths, blocked extents,
+    ctx.set_option("padded_rows", 1)                      # the padded copy of col_idx
     try:
         A = ctx.wrap_device(n, n, int(ci1.size), d_rp.data_ptr(), d_ci.data_ptr(), keep=(d_rp, d_ci))
         C = ctx.multiply(A, A)
@@ -465,10 +528,10 @@ def test_rewritten_operand_needs_invalidate(ctx):
         assert e.value.status == 1 and "invalidate" in str(e.value)          # BSPGEMM_ERR_INVALID
         # (2) with invalidate: the new product, tables rebuilt, the check is satisfied
         A.invalidate()
-        assert A.uses_blocked_table == -1
+        assert A.uses_blocked_table == -1 and A.uses_padded_rows == -1
         C = ctx.multiply(A, A)
         st = ctx.stats()
-        assert st["checked"] == 1 and st["prepass_kernel"] == 1
+        assert st["checked"] == 1 and st["prepass_kernel"] == 1 and st["padded_rows"] == 1
         crp, cci = C.download(); C.free()
         erp, eci = O.spgemm(rp2, ci2, rp2, ci2, n)
         assert_same(crp, cci, erp, eci)
@@ -476,6 +539,7 @@ def test_rewritten_operand_needs_invalidate(ctx):
     finally:
         ctx.set_option("check", old_chk)
         ctx.set_option("blocked_extents", old_blk)
+        ctx.set_option("padded_rows", old_pad)
 
 
 def test_mostly_empty_rows(ctx):
@@ -644,6 +708,7 @@ def test_baseline_cfg3_rmat_scale22_full_size(ctx):
     st = ctx.stats()
     crp, _ = C.download(col_idx=False)
     assert st["products"] == O.count_products(rp, ci, rp) == 1336443900
+    assert st["padded_rows"] == 0 and st["prepass_kernel"] == 1       # what the bench line runs: the blocked table over B.col_idx itself
     assert C.nnz == crp[-1] == st["nnz_c"] == 1336366087          # the number bench.py prints
     assert crp[0] == 0 and np.all(np.diff(crp) >= 0)
     cols = bdist.device_tensor(C.col_idx_device, C.nnz, torch.int32, dev)
