@@ -312,7 +312,7 @@ extern "C" bspgemm_status bspgemm_matrix_invalidate(bspgemm_matrix *m)
 
 extern "C" const char *bspgemm_build_info(void)
 {
-    return "libbspgemm: HIP kernels for gfx950 only; flows upper-bound (default), exact; "
+    return "libbspgemm: HIP kernels for gfx950 only; flows upper-bound (default), exact; small-product path; "
            "timing-only ablation switches: none (BSP_ABLATE=0); tuning constants are compile-time";
 }
 

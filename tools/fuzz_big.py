@@ -1,10 +1,11 @@
 """One-off parity campaign beyond tests/: mid-size random products (R-MAT of several skews, power-law,
 uniform, rectangular with hubs) against the CPU oracle, plain and masked.  usage: fuzz_big.py [cases]"""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, "binary-spgemm_amd")
-sys.path.insert(0, "tests")
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "binary-spgemm_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch, bspgemm, gen
 from oracle import oracle as O
 
@@ -15,6 +16,10 @@ t0 = time.perf_counter()
 for k in range(cases):
     kind = k % 5
     ctx.set_flow(("upper-bound", "exact", "auto")[(k // 5) % 3])
+    # round 4: the per-operand paths in rotation as well (decided when an operand is first used as B: fresh operands per case)
+    ctx.set_option("padded_rows", (0, 1, -1)[(k // 3) % 3])
+    ctx.set_option("blocked_extents", (-1, 1, 0)[(k // 7) % 3])
+    ctx.set_option("small_path", (-1, 0, 1)[(k // 11) % 3])
     if kind == 0:
         sc = int(rng.integers(12, 17)); abc = [(0.30, 0.25, 0.25), (0.45, 0.22, 0.22), (0.57, 0.19, 0.19)][k // 5 % 3]
         rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(4, 24)), abc, seed=1000 + k)
@@ -55,8 +60,9 @@ for k in range(cases):
             frp, fci = O.spgemm_masked(rp, ci, b_rp, b_ci, ncols, rp, ci)
             mok = np.array_equal(mrp, frp) and np.array_equal(mci, fci)
             M.free()
-    print("case %2d %-11s kind %d rows %7d cols %9d products %.3g nnz %.3g  %s %s" %
-          (k, ("upper-bound", "exact", "auto")[(k // 5) % 3], kind, n, ncols, st["products"], erp[-1], "OK" if ok else "MISMATCH", "" if mok else "MASKED MISMATCH"), flush=True)
+    print("case %2d %-11s pad %d blk %d small %d kind %d rows %7d cols %9d products %.3g nnz %.3g  %s %s" %
+          (k, ("upper-bound", "exact", "auto")[(k // 5) % 3], st["padded_rows"], st["prepass_kernel"], st["small_path"], kind, n, ncols, st["products"], erp[-1],
+           "OK" if ok else "MISMATCH", "" if mok else "MASKED MISMATCH"), flush=True)
     C.free()
     if B is not A:
         B.free()
