@@ -32,8 +32,12 @@ constexpr int kBigMinWaves = 4;
 constexpr int kDenseMaxWords = 16384;        // 64-bit words per window = 2^20 columns = 128 KiB
 constexpr int kMidMaxWords = 4096;           // 4096 words = 2^18 columns = 32 KiB
 constexpr int kDenseWordBits = 12;           // 64-column words with at least this many outputs are emitted by a whole wave
-constexpr int kDenseTilePerThread = 32;      // products per thread and tile (multiple of 4: one wave scans the tile's words)
-constexpr int kDenseInFlight = 8;            // B.col_idx loads a thread keeps in flight
+constexpr int kDenseQuadsPerThreadBig = 16;  // quads (16-byte pieces of a B row) per thread and tile: 64 / 32 products
+constexpr int kDenseQuadsPerThreadMid = 8;   //   (the small shape's four workgroups share the CU's LDS: a smaller plan)
+constexpr int kDenseInFlightBig = 8;         // 16-byte B.col_idx loads a thread keeps in flight
+constexpr int kDenseInFlightMid = 4;         //   (64 VGPRs)
+
+struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
 
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
@@ -41,7 +45,7 @@ constexpr int kDenseInFlight = 8;            // B.col_idx loads a thread keeps i
 // set in P is set in K, and K is what gets read out.
 template <bool MASKED, int kDenseThreads>
 __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ? kBigMinWaves : kMidMinWaves)) void k_dense_rows(const int2 *__restrict__ ab,
-                                                              const int *__restrict__ Bcol,
+                                                              const int *__restrict__ Bcol, int nnzB,
                                                               int cols, int wwords,
                                                               const RowRec *__restrict__ rec,
                                                               const long long *__restrict__ recpre,
@@ -58,17 +62,21 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     u64 *bm = MASKED ? bmP + wwords : bmP;                             // what is read out (K or P)
     u32 *bmK32 = reinterpret_cast<u32 *>(bm);
     constexpr int kWaves = kDenseThreads / 64;
-    constexpr int kTile = kDenseThreads * kDenseTilePerThread;   // products per tile
-    constexpr int kTileWords = kTile / 32;
-    constexpr int kInFlight = kDenseInFlight;                      // B.col_idx loads a thread keeps in flight
+    constexpr int kQPT = kDenseThreads == kDenseThreadsBig ? kDenseQuadsPerThreadBig : kDenseQuadsPerThreadMid;
+    constexpr int kTileQ = kDenseThreads * kQPT;                   // quads per tile
+    constexpr int kTileWords = kTileQ / 32;
+    constexpr int kInFlight = kDenseThreads == kDenseThreadsBig ? kDenseInFlightBig : kDenseInFlightMid;   // 16-byte loads a thread keeps in flight
     static_assert(kTileWords % 64 == 0 && kTileWords <= kDenseThreads, "one wave scans the tile's words, blocked");
+    static_assert(kQPT % kInFlight == 0, "whole steps");
     __shared__ int wtot[kWaves], wcnt[kWaves];
     __shared__ long long wsum[kWaves];
-    __shared__ int sd[kDenseBatch];             // non-empty sources of the batch: B address - product index in the tile
-    __shared__ u32 tb[kTileWords];              // starts of the sources inside the current tile
-    __shared__ int tpre[kTileWords];            // (sources begun before word w) - 1
+    __shared__ int2 sd[kDenseBatch];            // non-empty sources of the batch: (B address - 4 * first quad, B end address)
+    __shared__ u32 tb[kTileWords];              // starts of the sources inside the tile being planned (all zero between tiles)
+    __shared__ u32 tw[2][kTileWords];           // ... as the gather reads them: two tiles, so that the next plan never waits for the slowest gather
+    __shared__ int tpre[2][kTileWords];         // (sources begun before word w) - 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < (MASKED ? 2 * wwords : wwords); t += kDenseThreads) bmP[t] = 0ull;
+    if (tid < kTileWords) tb[tid] = 0u;
     __syncthreads();
 
     const RowRec q = rec[blockIdx.x];
@@ -79,99 +87,142 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     const int nwin = (int)(((long long)cols + W - 1) / W);
     int total = 0;
 
-    // A row of one batch and one tile keeps its gather plan (sd, tb, tpre in LDS) for the later windows:
+    // A row of one batch and one tile keeps its gather plan (sd, tw, tpre in LDS) for the later windows:
     // they then start at the loads -- no extents, no block scan, no tile bitmap, none of their barriers
     // (on a wide matrix most rows of the small shape are like that, and each of these phases is a
     // latency the row's few waves cannot hide).
-    long long PB = 0;
+    long long QB = 0;                                                  // quads of the batch
     bool plan_kept = false;                                            // uniform
+    int buf = 0;                                                       // which of tw / tpre the current tile reads
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         const int lo32 = (int)lo;
         for (int ja = a0; ja < a1; ja += kDenseBatch) {
-            // One source (A-nonzero) per thread.  A block scan of the B-row lengths gives every source
-            // its offset in the batch's product order; the non-empty sources are squeezed into a list
-            // of (B address - product offset).  The products are then taken in TILES of kTile: a
-            // "starts" bitmap over the tile marks where each source begins, one wave turns its words
-            // into running source counts, and product p finds its source by rank -- word, count,
-            // popcount: two independent LDS reads and a dependent one, the same for B rows of 3 and of
-            // 30000 entries (round 1 walked long sources by segments and searched the short ones'
-            // offsets with ten dependent LDS reads per product) -- so that every thread can keep
-            // kInFlight B.col_idx loads in the air.
+            // One source (A-nonzero) per thread.  The unit of the gather is the QUAD: four consecutive entries of one
+            // B row, one 16-byte load.  A block scan of the sources' quad counts gives every source its place in the
+            // batch's quad order; the non-empty sources are squeezed into a list of (B address - 4 * first quad, B end).
+            // The quads are taken in TILES of kTileQ: a "starts" bitmap over the tile marks where each source begins,
+            // one wave turns its words into running source counts, and quad t finds its source by rank -- word, count,
+            // popcount: two independent LDS reads and a dependent one, the same for B rows of 3 and of 30000 entries
+            // -- so that every thread keeps kInFlight 16-byte loads in the air.  (Rounds 1-3 looked up every PRODUCT
+            // this way, three LDS reads and one 4-byte load each; the heavy classes were bound by exactly those, not by
+            // memory: profiles/r04_heavy_ablation.log.)
+            // The last quad of a source is the four entries that END at the row's end: it overlaps the quad before it
+            // (the accumulator is a set: inserting a column twice is harmless) and for a source of one to three entries
+            // it begins before the source -- those lanes are masked.  No load ever passes the end of B.col_idx.
             int2 e = make_int2(0, 0);
-            int len = 0, cidx = 0;
-            long long excl = 0;
+            int nq = 0, cidx = 0;
+            long long qexcl = 0;
             if (!plan_kept) {
                 if (ja + tid < a1) e = ab[ja + tid];
-                len = e.y;
-                const int inc = wave_incl_scan(len);
-                const u64 nonempty = __ballot(len > 0);
+                nq = (int)(((u32)e.y + 3u) >> 2);
+                const int inc = wave_incl_scan(nq);
+                const u64 nonempty = __ballot(nq > 0);
                 if (lane == 63) wsum[wave] = (long long)inc;
                 if (lane == 0) wcnt[wave] = __popcll(nonempty);
                 __syncthreads();
-                excl = (long long)(inc - len);
-                PB = 0;
+                qexcl = (long long)(inc - nq);
+                QB = 0;
                 cidx = __popcll(nonempty & mask_lt(lane));
                 for (int k = 0; k < kWaves; k++) {
                     const long long t = wsum[k];
                     const int c = wcnt[k];
-                    if (k < wave) { excl += t; cidx += c; }
-                    PB += t;
+                    if (k < wave) { qexcl += t; cidx += c; }
+                    QB += t;
                 }
+                if (nq > 0) sd[cidx] = make_int2((int)((u32)e.x - 4u * (u32)qexcl), e.x + e.y);   // (mod 2^32: the sum is a B address again)
+                if (QB == 0) __syncthreads();                          // (no tile: nothing else orders this batch's wsum reads before the next batch's writes)
             }
-            for (long long T0 = 0; T0 < PB; T0 += kTile) {
+            int carry = -1;                                            // wave 0: (sources begun before the tile) - 1
+            for (long long T0 = 0; T0 < QB; T0 += kTileQ) {
                 if (!plan_kept) {
-                __syncthreads();                // wcnt / tile arrays are free again
-                if (tid < kTileWords) tb[tid] = 0u;
-                const u64 earlier = __ballot(len > 0 && excl < T0);    // sources that began before the tile
-                if (lane == 0) wcnt[wave] = __popcll(earlier);
-                __syncthreads();
-                if (len > 0 && excl < T0 + kTile && excl + len > T0) {  // the source has products in this tile
-                    const int rel = (int)(excl - T0);                  // > -len: fits an int
-                    sd[cidx] = e.x - rel;                              // B address = sd + product index in the tile
-                    if (rel >= 0) atomicOr(&tb[rel >> 5], 1u << (rel & 31));
-                }
-                __syncthreads();
-                if (wave == 0) {
-                    int before = -1;                                   // rank of a product's source - bits up to it
-                    for (int k = 0; k < kWaves; k++) before += wcnt[k];
-                    constexpr int WPL = kTileWords / 64;               // words per lane, blocked
-                    int c[WPL], run = 0;
-#pragma unroll
-                    for (int k = 0; k < WPL; k++) { c[k] = run; run += __popc(tb[lane * WPL + k]); }
-                    const int wi = wave_incl_scan(run);
-#pragma unroll
-                    for (int k = 0; k < WPL; k++) tpre[lane * WPL + k] = before + wi - run + c[k];
-                }
-                __syncthreads();
-                }
-                const int np = (PB - T0 < kTile) ? (int)(PB - T0) : kTile;
-                for (int k0 = 0; k0 < np; k0 += kInFlight * kDenseThreads) {
-                    int addr[kInFlight];
-                    bool ok[kInFlight];
-#pragma unroll
-                    for (int u = 0; u < kInFlight; u++) {
-                        const int p = k0 + u * kDenseThreads + tid;
-                        ok[u] = p < np;
-                        const int pp = ok[u] ? p : 0;
-                        const u32 w = tb[pp >> 5];
-                        const int src = tpre[pp >> 5] + __popc(w & ((2u << (pp & 31)) - 1u));
-                        addr[u] = sd[src < 0 ? 0 : src] + pp;
+                    buf ^= 1;
+                    if (nq > 0 && qexcl >= T0 && qexcl < T0 + kTileQ) {    // the source begins in this tile
+                        const int rel = (int)(qexcl - T0);
+                        atomicOr(&tb[rel >> 5], 1u << (rel & 31));
                     }
-                    int cv[kInFlight];
+                    __syncthreads();
+                    if (wave == 0) {
+                        constexpr int WPL = kTileWords / 64;               // words per lane, blocked
+                        u32 x[WPL];
+                        int c[WPL], run = 0;
 #pragma unroll
-                    for (int u = 0; u < kInFlight; u++)
-                        cv[u] = ok[u] ? Bcol[addr[u]] : -1;
+                        for (int k = 0; k < WPL; k++) {
+                            x[k] = tb[lane * WPL + k];
+                            tb[lane * WPL + k] = 0u;
+                            c[k] = run;
+                            run += __popc(x[k]);
+                        }
+                        const int wi = wave_incl_scan(run);
+#pragma unroll
+                        for (int k = 0; k < WPL; k++) {
+                            tw[buf][lane * WPL + k] = x[k];
+                            tpre[buf][lane * WPL + k] = carry + wi - run + c[k];
+                        }
+                        carry += wave_bcast(wi, 63);
+                    }
+                    __syncthreads();
+                }
+                const int nqt = (QB - T0 < kTileQ) ? (int)(QB - T0) : kTileQ;
+                const u32 *twb = tw[buf];
+                const int *tpb = tpre[buf];
+                const u32 T0lo = 4u * (u32)T0;
+                for (int k0 = 0; k0 < nqt; k0 += kInFlight * kDenseThreads) {
+                    int base[kInFlight];
+                    u32 vmask[kInFlight];                              // lanes of the quad that are entries of this source not yet taken
 #pragma unroll
                     for (int u = 0; u < kInFlight; u++) {
-                        const u32 c = (u32)(cv[u] - lo32);                 // columns below the window wrap to huge values
-                        if (ok[u] && c < (u32)W) atomicOr(&bm32[c >> 5], 1u << (c & 31));
+                        const int t = k0 + u * kDenseThreads + tid;
+                        const bool ok = t < nqt;
+                        const int tt = ok ? t : 0;
+                        const u32 w = twb[tt >> 5];
+                        const int src = tpb[tt >> 5] + __popc(w & ((2u << (tt & 31)) - 1u));
+                        const int2 sq = sd[src < 0 ? 0 : src];
+                        const int qs = (int)((u32)sq.x + T0lo + 4u * (u32)tt);   // first entry of the quad
+                        int b = qs < sq.y - 4 ? qs : sq.y - 4;
+                        b = b < 0 ? 0 : b;
+                        base[u] = b;
+                        u32 m = 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) m |= (ok && b + k >= qs && b + k < sq.y) ? (1u << k) : 0u;
+                        vmask[u] = m;
+                    }
+                    Int4U cv[kInFlight];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; u++) {
+                        if (nnzB >= 4) {                               // (uniform)
+                            cv[u] = *reinterpret_cast<const Int4U *>(Bcol + base[u]);      // only dword aligned
+                        } else {                                       // a B of one to three entries: base is 0, no vector load fits
+                            cv[u].x = Bcol[0];
+                            cv[u].y = nnzB > 1 ? Bcol[1] : 0;
+                            cv[u].z = nnzB > 2 ? Bcol[2] : 0;
+                            cv[u].w = 0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kInFlight; u++) {
+                        // the quad's columns ascend: entries of one 32-column word are neighbours, and the first of each
+                        // run ORs the whole run -- one LDS atomic per word touched instead of one per product (the dense
+                        // heads of hub B rows put up to 32 lanes' products into ONE word: same-address atomics serialise)
+                        const u32 c0 = (u32)(cv[u].x - lo32), c1 = (u32)(cv[u].y - lo32), c2 = (u32)(cv[u].z - lo32), c3 = (u32)(cv[u].w - lo32);
+                        const bool i0 = (vmask[u] & 1u) && c0 < (u32)W, i1 = (vmask[u] & 2u) && c1 < (u32)W;   // (columns below the window wrap to huge values)
+                        const bool i2 = (vmask[u] & 4u) && c2 < (u32)W, i3 = (vmask[u] & 8u) && c3 < (u32)W;
+                        const u32 w0 = i0 ? c0 >> 5 : 0xfffffff0u, w1 = i1 ? c1 >> 5 : 0xfffffff1u;
+                        const u32 w2 = i2 ? c2 >> 5 : 0xfffffff2u, w3 = i3 ? c3 >> 5 : 0xfffffff3u;
+                        const u32 b0 = 1u << (c0 & 31), b1 = 1u << (c1 & 31), b2 = 1u << (c2 & 31), b3 = 1u << (c3 & 31);
+                        const u32 m2 = b2 | (w3 == w2 ? b3 : 0u);
+                        const u32 m1 = b1 | (w2 == w1 ? m2 : 0u);
+                        const u32 m0 = b0 | (w1 == w0 ? m1 : 0u);
+                        if (i0) atomicOr(&bm32[w0], m0);
+                        if (i1 && w1 != w0) atomicOr(&bm32[w1], m1);
+                        if (i2 && w2 != w1) atomicOr(&bm32[w2], m2);
+                        if (i3 && w3 != w2) atomicOr(&bm32[w3], b3);
                     }
                 }
             }
             __syncthreads();
         }
-        if (win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && PB <= kTile && PB > 0;
+        if (win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && QB <= kTileQ && QB > 0;
         if (MASKED) {
             // keep the product bits that F's row admits, then wipe P for the next window / row
             const int f0 = Frow[i], f1 = Frow[i + 1];
@@ -253,7 +304,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
 }
 
 template <bool MASKED, int THREADS>
-static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, const RowRec *rec,
+static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, long long nnzB, int cols, const RowRec *rec,
                                     const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt,
                                     const int *Frow, const int *Fcol, hipStream_t s)
 {
@@ -275,7 +326,7 @@ static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, int cols, c
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL((k_dense_rows<MASKED, THREADS>), dim3(nrows), dim3(THREADS), bytes, s, ab, Bcol,
-                       cols, (int)words, rec, recpre, row_begin, tmp, cnt, Frow, Fcol);
+                       (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, (int)words, rec, recpre, row_begin, tmp, cnt, Frow, Fcol);
     return hipGetLastError();
 }
 
@@ -302,20 +353,20 @@ void launch_order_heavy(const RowRec *rec, const long long *recpre, int n, RowRe
     hipLaunchKernelGGL(k_order_heavy, dim3((n + 255) / 256), dim3(256), 0, s, rec, recpre, n, rec_out, pre_out);
 }
 
-hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
+hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, long long nnzB, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s)
 {
     if (mid)
-        return launch_dense_impl<false, kDenseThreadsMid>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
-    return launch_dense_impl<false, kDenseThreadsBig>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
+        return launch_dense_impl<false, kDenseThreadsMid>(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
+    return launch_dense_impl<false, kDenseThreadsBig>(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
 }
 
-hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
+hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, long long nnzB, int cols,
                                     const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                                     int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s)
 {
-    return launch_dense_impl<true, kDenseThreadsBig>(ab, Bcol, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
+    return launch_dense_impl<true, kDenseThreadsBig>(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, Frow, Fcol, s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -361,7 +412,6 @@ constexpr int kCompactBatch = 256;       // rows staged in LDS at a time
 constexpr int kCompactInFlight = 4;      // 16-B groups a thread has in flight (8 measured slower)
 constexpr int kCompactSparseRows = 4096; // a chunk spanning more rows than this is searched per output
 
-struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,

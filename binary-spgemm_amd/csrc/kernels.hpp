@@ -148,7 +148,7 @@ void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recp
                         const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s);
 
 // numeric phase, one workgroup per heavy row (windowed dense LDS bitmap); mid: the 512-thread shape
-hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, int cols,
+hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, long long nnzB, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 
@@ -158,7 +158,7 @@ void launch_order_heavy(const RowRec *rec, const long long *recpre, int n, RowRe
 
 // masked variant: C = F .* (A*B); every non-empty row goes through the window kernel, which
 // keeps only the product bits that F's row (absolute row id, F.row_ptr/F.col_idx) admits
-hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, int cols,
+hipError_t launch_dense_rows_masked(const int2 *ab, const int *Bcol, long long nnzB, int cols,
                                     const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                                     int *tmp, int *cnt, const int *Frow, const int *Fcol, hipStream_t s);
 

@@ -191,7 +191,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             } else {
                 const long long *hpre = ctx->recpre + bin_start[b];
                 hub_order(ctx, b, n, rec, hpre, sx);
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->cols, rec, hpre, n,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->nnz, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
@@ -360,13 +360,13 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
                 launch_wave_rows(b, levels, ctx->ab, Bcol, B->cols, rec, recpre, nullptr, n, row_begin,
                                  ctx->tmp, ctx->cnt, ctx->d_err, sx);
             else if (!Fm)
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->cols, rec, recpre, n, row_begin, ctx->tmp,
+                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->nnz, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
             else if (b <= kWaveBins && wave_masked_supported(B->cols))
                 launch_wave_masked(b, ctx->ab, Bcol, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
                                    row_begin, ctx->tmp, ctx->cnt, sx);
             else
-                HIPCHK_B(launch_dense_rows_masked(ctx->ab, Bcol, B->cols, rec, recpre, n, row_begin,
+                HIPCHK_B(launch_dense_rows_masked(ctx->ab, Bcol, B->nnz, B->cols, rec, recpre, n, row_begin,
                                                   ctx->tmp, ctx->cnt, Fm->d_row_ptr, Fm->d_col_idx, sx));
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][1], sx));
         }
