@@ -482,7 +482,7 @@ static void fill_stats(const bspgemm_context::StatSlot &sl, bspgemm_stats &st)
     st.bins = kNumBins;
     for (int b = 0; b < kNumBins; b++) {
         st.rows_per_bin[b] = sl.h.bin_count[b];
-        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : (b == kMidBin ? sl.mid_cap : 64 * kWaveChunks[b]));
+        st.bin_cap[b] = b == 0 ? 0 : (b == kDenseBin ? 0x7fffffff : (b == kMidBin ? sl.mid_cap : (b == kRankBin ? (sl.rank_cap > kMaxWaveCap ? sl.rank_cap : kMaxWaveCap) : 64 * kWaveChunks[b])));
     }
     st.flow = sl.flow;
     st.prepass_kernel = sl.prepass_kernel;

@@ -16,6 +16,7 @@
 // upper-bound-placed rows into C.col_idx.
 #include "kernels.hpp"
 #include "wave.hpp"
+#include <stdlib.h>
 
 namespace bsp {
 
@@ -39,6 +40,175 @@ constexpr int kDenseInFlightMid = 4;         //   (64 VGPRs)
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
 
+// ---------------------------------------------------------------------------------------
+// The heavy rows' GATHER, shared by the windowed kernel and the rank kernel below: one sweep over all the products
+// of the row, `ins(quad, valid lanes)` called once per quad.
+//
+// One source (A-nonzero) per thread, kThreads at a time (a "batch").  The unit is the QUAD: four consecutive entries
+// of one B row, one 16-byte load.  A block scan of the sources' quad counts gives every source its place in the batch's
+// quad order; the non-empty sources are squeezed into a list of (B address - 4 * first quad, B end).  The quads are
+// taken in TILES of kThreads * kQPT: a "starts" bitmap over the tile marks where each source begins, one wave turns its
+// words into running source counts, and quad t finds its source by rank -- word, count, popcount: two independent LDS
+// reads and a dependent one, the same for B rows of 3 and of 30000 entries -- so that every thread keeps kInFlight
+// 16-byte loads in the air.  (Rounds 1-3 looked up every PRODUCT this way, three LDS reads and one 4-byte load each;
+// the heavy classes were bound by exactly those, not by memory: profiles/r04_heavy_ablation.log.)
+// The last quad of a source is the four entries that END at the row's end: it overlaps the quad before it (the
+// accumulators are sets: inserting a column twice is harmless) and for a source of one to three entries it begins
+// before the source -- those lanes are masked.  No load ever passes the end of B.col_idx.
+// A row of one batch and one tile KEEPS its plan (sd, tw, tpre in LDS) for the later sweeps: they then start at the
+// loads -- no extents, no block scan, no tile bitmap, none of their barriers (each of these phases is a latency the
+// row's few waves cannot hide).
+struct GatherState {
+    long long QB = 0;            // quads of the batch
+    bool plan_kept = false;      // uniform
+    int buf = 0;                 // which of tw / tpre the current tile reads
+};
+
+template <int kThreads, int kQPT>
+struct GatherLds {
+    static constexpr int kWaves = kThreads / 64;
+    static constexpr int kTileQ = kThreads * kQPT;                 // quads per tile
+    static constexpr int kTileWords = kTileQ / 32;
+    static_assert(kTileWords % 64 == 0 && kTileWords <= kThreads, "one wave scans the tile's words, blocked");
+    int wcnt[kWaves];
+    long long wsum[kWaves];
+    int2 sd[kThreads];            // non-empty sources of the batch: (B address - 4 * first quad, B end address)
+    u32 tb[kTileWords];           // starts of the sources inside the tile being planned (all zero between tiles)
+    u32 tw[2][kTileWords];        // ... as the gather reads them: two tiles, so that the next plan never waits for the slowest gather
+    int tpre[2][kTileWords];      // (sources begun before word w) - 1
+};
+
+// before the kernel's first barrier
+template <int kThreads, int kQPT>
+__device__ __forceinline__ void gather_init(GatherLds<kThreads, kQPT> &L)
+{
+    if ((int)threadIdx.x < GatherLds<kThreads, kQPT>::kTileWords) L.tb[threadIdx.x] = 0u;
+}
+
+template <int kThreads, int kQPT, int kInFlight, typename Ins>
+__device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, GatherState &g, const int2 *__restrict__ ab,
+                                             const int *__restrict__ Bcol, int nnzB, int a0, int a1, bool first_sweep, Ins ins)
+{
+    using LT = GatherLds<kThreads, kQPT>;
+    constexpr int kWaves = LT::kWaves, kTileQ = LT::kTileQ, kTileWords = LT::kTileWords;
+    static_assert(kQPT % kInFlight == 0, "whole steps");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int ja = a0; ja < a1; ja += kThreads) {
+        int2 e = make_int2(0, 0);
+        int nq = 0, cidx = 0;
+        long long qexcl = 0;
+        if (!g.plan_kept) {
+            if (ja + tid < a1) e = ab[ja + tid];
+            nq = (int)(((u32)e.y + 3u) >> 2);
+            const int inc = wave_incl_scan(nq);
+            const u64 nonempty = __ballot(nq > 0);
+            if (lane == 63) L.wsum[wave] = (long long)inc;
+            if (lane == 0) L.wcnt[wave] = __popcll(nonempty);
+            __syncthreads();
+            qexcl = (long long)(inc - nq);
+            g.QB = 0;
+            cidx = __popcll(nonempty & mask_lt(lane));
+            for (int k = 0; k < kWaves; k++) {
+                const long long t = L.wsum[k];
+                const int c = L.wcnt[k];
+                if (k < wave) { qexcl += t; cidx += c; }
+                g.QB += t;
+            }
+            if (nq > 0) L.sd[cidx] = make_int2((int)((u32)e.x - 4u * (u32)qexcl), e.x + e.y);   // (mod 2^32: the sum is a B address again)
+            if (g.QB == 0) __syncthreads();                        // (no tile: nothing else orders this batch's wsum reads before the next batch's writes)
+        }
+        int carry = -1;                                            // wave 0: (sources begun before the tile) - 1
+        for (long long T0 = 0; T0 < g.QB; T0 += kTileQ) {
+            if (!g.plan_kept) {
+                g.buf ^= 1;
+                if (nq > 0 && qexcl >= T0 && qexcl < T0 + kTileQ) {    // the source begins in this tile
+                    const int rel = (int)(qexcl - T0);
+                    atomicOr(&L.tb[rel >> 5], 1u << (rel & 31));
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    constexpr int WPL = kTileWords / 64;               // words per lane, blocked
+                    u32 x[WPL];
+                    int c[WPL], run = 0;
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) {
+                        x[k] = L.tb[lane * WPL + k];
+                        L.tb[lane * WPL + k] = 0u;
+                        c[k] = run;
+                        run += __popc(x[k]);
+                    }
+                    const int wi = wave_incl_scan(run);
+#pragma unroll
+                    for (int k = 0; k < WPL; k++) {
+                        L.tw[g.buf][lane * WPL + k] = x[k];
+                        L.tpre[g.buf][lane * WPL + k] = carry + wi - run + c[k];
+                    }
+                    carry += wave_bcast(wi, 63);
+                }
+                __syncthreads();
+            }
+            const int nqt = (g.QB - T0 < kTileQ) ? (int)(g.QB - T0) : kTileQ;
+            const u32 *twb = L.tw[g.buf];
+            const int *tpb = L.tpre[g.buf];
+            const u32 T0lo = 4u * (u32)T0;
+            for (int k0 = 0; k0 < nqt; k0 += kInFlight * kThreads) {
+                int base[kInFlight];
+                u32 vmask[kInFlight];                              // lanes of the quad that are entries of this source not yet taken
+#pragma unroll
+                for (int u = 0; u < kInFlight; u++) {
+                    const int t = k0 + u * kThreads + tid;
+                    const bool ok = t < nqt;
+                    const int tt = ok ? t : 0;
+                    const u32 w = twb[tt >> 5];
+                    const int src = tpb[tt >> 5] + __popc(w & ((2u << (tt & 31)) - 1u));
+                    const int2 sq = L.sd[src < 0 ? 0 : src];
+                    const int qs = (int)((u32)sq.x + T0lo + 4u * (u32)tt);   // first entry of the quad
+                    int b = qs < sq.y - 4 ? qs : sq.y - 4;
+                    b = b < 0 ? 0 : b;
+                    base[u] = b;
+                    u32 m = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) m |= (ok && b + k >= qs && b + k < sq.y) ? (1u << k) : 0u;
+                    vmask[u] = m;
+                }
+                Int4U cv[kInFlight];
+#pragma unroll
+                for (int u = 0; u < kInFlight; u++) {
+                    if (nnzB >= 4) {                               // (uniform)
+                        cv[u] = *reinterpret_cast<const Int4U *>(Bcol + base[u]);      // only dword aligned
+                    } else {                                       // a B of one to three entries: base is 0, no vector load fits
+                        cv[u].x = Bcol[0];
+                        cv[u].y = nnzB > 1 ? Bcol[1] : 0;
+                        cv[u].z = nnzB > 2 ? Bcol[2] : 0;
+                        cv[u].w = 0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kInFlight; u++) ins(cv[u], vmask[u]);
+            }
+        }
+        __syncthreads();
+    }
+    if (first_sweep) g.plan_kept = (a1 - a0 <= kThreads) && g.QB <= kTileQ && g.QB > 0;
+}
+
+// One quad into a bitmap: entry k goes to bit b_k of word w_k when i_k.  The quad's columns ascend, so the entries of one
+// word are neighbours, and the first of each run ORs the whole run -- one LDS atomic per word touched instead of one per
+// product (the dense heads of hub B rows put up to 32 lanes' products into ONE word: same-address atomics serialise).
+// Correct for any order (an unsorted B row only merges less).
+__device__ __forceinline__ void insert_quad(u32 *tgt, bool i0, bool i1, bool i2, bool i3, u32 w0, u32 w1, u32 w2, u32 w3,
+                                            u32 b0, u32 b1, u32 b2, u32 b3)
+{
+    w0 = i0 ? w0 : 0xfffffff0u, w1 = i1 ? w1 : 0xfffffff1u, w2 = i2 ? w2 : 0xfffffff2u, w3 = i3 ? w3 : 0xfffffff3u;
+    const u32 m2 = b2 | (w3 == w2 ? b3 : 0u);
+    const u32 m1 = b1 | (w2 == w1 ? m2 : 0u);
+    const u32 m0 = b0 | (w1 == w0 ? m1 : 0u);
+    if (i0) atomicOr(&tgt[w0], m0);
+    if (i1 && w1 != w0) atomicOr(&tgt[w1], m1);
+    if (i2 && w2 != w1) atomicOr(&tgt[w2], m2);
+    if (i3 && w3 != w2) atomicOr(&tgt[w3], b3);
+}
+
 // MASKED: C = F .* (A*B) (SpGEMM_masked, final/SpGEMM_mpi_omp.c:232-288).  The reference presets
 // its flag array so that only columns of F's row can be appended (:253-255); here the window
 // holds two bitmaps, P (products) and K (kept): after the gather every column of F's row that is
@@ -55,7 +225,6 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                                                               const int *__restrict__ Frow,
                                                               const int *__restrict__ Fcol)
 {
-    constexpr int kDenseBatch = kDenseThreads;   // A-nonzeros whose products are flattened at a time
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     u64 *bmP = reinterpret_cast<u64 *>(lds_raw);                       // products
     u32 *bm32 = reinterpret_cast<u32 *>(lds_raw);
@@ -63,20 +232,12 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     u32 *bmK32 = reinterpret_cast<u32 *>(bm);
     constexpr int kWaves = kDenseThreads / 64;
     constexpr int kQPT = kDenseThreads == kDenseThreadsBig ? kDenseQuadsPerThreadBig : kDenseQuadsPerThreadMid;
-    constexpr int kTileQ = kDenseThreads * kQPT;                   // quads per tile
-    constexpr int kTileWords = kTileQ / 32;
     constexpr int kInFlight = kDenseThreads == kDenseThreadsBig ? kDenseInFlightBig : kDenseInFlightMid;   // 16-byte loads a thread keeps in flight
-    static_assert(kTileWords % 64 == 0 && kTileWords <= kDenseThreads, "one wave scans the tile's words, blocked");
-    static_assert(kQPT % kInFlight == 0, "whole steps");
-    __shared__ int wtot[kWaves], wcnt[kWaves];
-    __shared__ long long wsum[kWaves];
-    __shared__ int2 sd[kDenseBatch];            // non-empty sources of the batch: (B address - 4 * first quad, B end address)
-    __shared__ u32 tb[kTileWords];              // starts of the sources inside the tile being planned (all zero between tiles)
-    __shared__ u32 tw[2][kTileWords];           // ... as the gather reads them: two tiles, so that the next plan never waits for the slowest gather
-    __shared__ int tpre[2][kTileWords];         // (sources begun before word w) - 1
+    __shared__ GatherLds<kDenseThreads, kQPT> G;
+    __shared__ int wtot[kWaves];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < (MASKED ? 2 * wwords : wwords); t += kDenseThreads) bmP[t] = 0ull;
-    if (tid < kTileWords) tb[tid] = 0u;
+    gather_init(G);
     __syncthreads();
 
     const RowRec q = rec[blockIdx.x];
@@ -87,142 +248,15 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     const int nwin = (int)(((long long)cols + W - 1) / W);
     int total = 0;
 
-    // A row of one batch and one tile keeps its gather plan (sd, tw, tpre in LDS) for the later windows:
-    // they then start at the loads -- no extents, no block scan, no tile bitmap, none of their barriers
-    // (on a wide matrix most rows of the small shape are like that, and each of these phases is a
-    // latency the row's few waves cannot hide).
-    long long QB = 0;                                                  // quads of the batch
-    bool plan_kept = false;                                            // uniform
-    int buf = 0;                                                       // which of tw / tpre the current tile reads
+    GatherState g;
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         const int lo32 = (int)lo;
-        for (int ja = a0; ja < a1; ja += kDenseBatch) {
-            // One source (A-nonzero) per thread.  The unit of the gather is the QUAD: four consecutive entries of one
-            // B row, one 16-byte load.  A block scan of the sources' quad counts gives every source its place in the
-            // batch's quad order; the non-empty sources are squeezed into a list of (B address - 4 * first quad, B end).
-            // The quads are taken in TILES of kTileQ: a "starts" bitmap over the tile marks where each source begins,
-            // one wave turns its words into running source counts, and quad t finds its source by rank -- word, count,
-            // popcount: two independent LDS reads and a dependent one, the same for B rows of 3 and of 30000 entries
-            // -- so that every thread keeps kInFlight 16-byte loads in the air.  (Rounds 1-3 looked up every PRODUCT
-            // this way, three LDS reads and one 4-byte load each; the heavy classes were bound by exactly those, not by
-            // memory: profiles/r04_heavy_ablation.log.)
-            // The last quad of a source is the four entries that END at the row's end: it overlaps the quad before it
-            // (the accumulator is a set: inserting a column twice is harmless) and for a source of one to three entries
-            // it begins before the source -- those lanes are masked.  No load ever passes the end of B.col_idx.
-            int2 e = make_int2(0, 0);
-            int nq = 0, cidx = 0;
-            long long qexcl = 0;
-            if (!plan_kept) {
-                if (ja + tid < a1) e = ab[ja + tid];
-                nq = (int)(((u32)e.y + 3u) >> 2);
-                const int inc = wave_incl_scan(nq);
-                const u64 nonempty = __ballot(nq > 0);
-                if (lane == 63) wsum[wave] = (long long)inc;
-                if (lane == 0) wcnt[wave] = __popcll(nonempty);
-                __syncthreads();
-                qexcl = (long long)(inc - nq);
-                QB = 0;
-                cidx = __popcll(nonempty & mask_lt(lane));
-                for (int k = 0; k < kWaves; k++) {
-                    const long long t = wsum[k];
-                    const int c = wcnt[k];
-                    if (k < wave) { qexcl += t; cidx += c; }
-                    QB += t;
-                }
-                if (nq > 0) sd[cidx] = make_int2((int)((u32)e.x - 4u * (u32)qexcl), e.x + e.y);   // (mod 2^32: the sum is a B address again)
-                if (QB == 0) __syncthreads();                          // (no tile: nothing else orders this batch's wsum reads before the next batch's writes)
-            }
-            int carry = -1;                                            // wave 0: (sources begun before the tile) - 1
-            for (long long T0 = 0; T0 < QB; T0 += kTileQ) {
-                if (!plan_kept) {
-                    buf ^= 1;
-                    if (nq > 0 && qexcl >= T0 && qexcl < T0 + kTileQ) {    // the source begins in this tile
-                        const int rel = (int)(qexcl - T0);
-                        atomicOr(&tb[rel >> 5], 1u << (rel & 31));
-                    }
-                    __syncthreads();
-                    if (wave == 0) {
-                        constexpr int WPL = kTileWords / 64;               // words per lane, blocked
-                        u32 x[WPL];
-                        int c[WPL], run = 0;
-#pragma unroll
-                        for (int k = 0; k < WPL; k++) {
-                            x[k] = tb[lane * WPL + k];
-                            tb[lane * WPL + k] = 0u;
-                            c[k] = run;
-                            run += __popc(x[k]);
-                        }
-                        const int wi = wave_incl_scan(run);
-#pragma unroll
-                        for (int k = 0; k < WPL; k++) {
-                            tw[buf][lane * WPL + k] = x[k];
-                            tpre[buf][lane * WPL + k] = carry + wi - run + c[k];
-                        }
-                        carry += wave_bcast(wi, 63);
-                    }
-                    __syncthreads();
-                }
-                const int nqt = (QB - T0 < kTileQ) ? (int)(QB - T0) : kTileQ;
-                const u32 *twb = tw[buf];
-                const int *tpb = tpre[buf];
-                const u32 T0lo = 4u * (u32)T0;
-                for (int k0 = 0; k0 < nqt; k0 += kInFlight * kDenseThreads) {
-                    int base[kInFlight];
-                    u32 vmask[kInFlight];                              // lanes of the quad that are entries of this source not yet taken
-#pragma unroll
-                    for (int u = 0; u < kInFlight; u++) {
-                        const int t = k0 + u * kDenseThreads + tid;
-                        const bool ok = t < nqt;
-                        const int tt = ok ? t : 0;
-                        const u32 w = twb[tt >> 5];
-                        const int src = tpb[tt >> 5] + __popc(w & ((2u << (tt & 31)) - 1u));
-                        const int2 sq = sd[src < 0 ? 0 : src];
-                        const int qs = (int)((u32)sq.x + T0lo + 4u * (u32)tt);   // first entry of the quad
-                        int b = qs < sq.y - 4 ? qs : sq.y - 4;
-                        b = b < 0 ? 0 : b;
-                        base[u] = b;
-                        u32 m = 0u;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) m |= (ok && b + k >= qs && b + k < sq.y) ? (1u << k) : 0u;
-                        vmask[u] = m;
-                    }
-                    Int4U cv[kInFlight];
-#pragma unroll
-                    for (int u = 0; u < kInFlight; u++) {
-                        if (nnzB >= 4) {                               // (uniform)
-                            cv[u] = *reinterpret_cast<const Int4U *>(Bcol + base[u]);      // only dword aligned
-                        } else {                                       // a B of one to three entries: base is 0, no vector load fits
-                            cv[u].x = Bcol[0];
-                            cv[u].y = nnzB > 1 ? Bcol[1] : 0;
-                            cv[u].z = nnzB > 2 ? Bcol[2] : 0;
-                            cv[u].w = 0;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < kInFlight; u++) {
-                        // the quad's columns ascend: entries of one 32-column word are neighbours, and the first of each
-                        // run ORs the whole run -- one LDS atomic per word touched instead of one per product (the dense
-                        // heads of hub B rows put up to 32 lanes' products into ONE word: same-address atomics serialise)
-                        const u32 c0 = (u32)(cv[u].x - lo32), c1 = (u32)(cv[u].y - lo32), c2 = (u32)(cv[u].z - lo32), c3 = (u32)(cv[u].w - lo32);
-                        const bool i0 = (vmask[u] & 1u) && c0 < (u32)W, i1 = (vmask[u] & 2u) && c1 < (u32)W;   // (columns below the window wrap to huge values)
-                        const bool i2 = (vmask[u] & 4u) && c2 < (u32)W, i3 = (vmask[u] & 8u) && c3 < (u32)W;
-                        const u32 w0 = i0 ? c0 >> 5 : 0xfffffff0u, w1 = i1 ? c1 >> 5 : 0xfffffff1u;
-                        const u32 w2 = i2 ? c2 >> 5 : 0xfffffff2u, w3 = i3 ? c3 >> 5 : 0xfffffff3u;
-                        const u32 b0 = 1u << (c0 & 31), b1 = 1u << (c1 & 31), b2 = 1u << (c2 & 31), b3 = 1u << (c3 & 31);
-                        const u32 m2 = b2 | (w3 == w2 ? b3 : 0u);
-                        const u32 m1 = b1 | (w2 == w1 ? m2 : 0u);
-                        const u32 m0 = b0 | (w1 == w0 ? m1 : 0u);
-                        if (i0) atomicOr(&bm32[w0], m0);
-                        if (i1 && w1 != w0) atomicOr(&bm32[w1], m1);
-                        if (i2 && w2 != w1) atomicOr(&bm32[w2], m2);
-                        if (i3 && w3 != w2) atomicOr(&bm32[w3], b3);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (win == 0) plan_kept = (a1 - a0 <= kDenseBatch) && QB <= kTileQ && QB > 0;
+        gather_sweep<kDenseThreads, kQPT, kInFlight>(G, g, ab, Bcol, nnzB, a0, a1, win == 0, [&](const Int4U &v, u32 vm) {
+            const u32 c0 = (u32)(v.x - lo32), c1 = (u32)(v.y - lo32), c2 = (u32)(v.z - lo32), c3 = (u32)(v.w - lo32);
+            insert_quad(bm32, (vm & 1u) && c0 < (u32)W, (vm & 2u) && c1 < (u32)W, (vm & 4u) && c2 < (u32)W, (vm & 8u) && c3 < (u32)W,   // (columns below the window wrap to huge values)
+                        c0 >> 5, c1 >> 5, c2 >> 5, c3 >> 5, 1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
+        });
         if (MASKED) {
             // keep the product bits that F's row admits, then wipe P for the next window / row
             const int f0 = Frow[i], f1 = Frow[i + 1];
@@ -303,6 +337,144 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     if (tid == 0) cnt[i - row_begin] = total;
 }
 
+// ---------------------------------------------------------------------------------------
+// RANK ROWS (class kRankBin): rows of 2048 < F_i <= kRankCap products when the column range is several windows of the
+// small dense shape.  The workgroup's LDS holds a two-level RANK bitmap instead of a dense one -- `top`, one bit per
+// 32-column word of the whole column range, and one 32-bit slot per SET top bit, addressed by the bit's rank (the
+// one-wave kernels' accumulator at workgroup scope, wave_rows.inc).  Slots are as many as the row has distinct words
+// (<= F_i), not as many as the matrix has columns: the row is done in TWO sweeps over its products (top bits; slot bits)
+// and ONE read-out proportional to the row, whatever the column count is -- the windowed shape runs one sweep and one
+// 4096-word read-out per 2^18 columns, four of each at 2^20 columns for a row that fills 1-2 % of every window, and
+// every one of them is a trip to memory that the row's eight waves wait for (profiles/r04_heavy_ablation.log).
+// LDS per workgroup: top (cols / 32 bits) + ranks (16 bits per top word) + kRankCap slots: 30 KiB at 2^20 columns,
+// beside the gather plan -- four workgroups per CU, as many as the windowed shape.
+constexpr int kRankThreads = 512;
+constexpr int kRankSlotsPerThread = kRankCap / kRankThreads;
+static_assert(kRankCap % kRankThreads == 0, "whole slots per thread");
+constexpr int kRankQPT = 8, kRankInFlight = 4;
+
+__global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__restrict__ ab, const int *__restrict__ Bcol, int nnzB,
+                                                               int cols, int topw,
+                                                               const RowRec *__restrict__ rec,
+                                                               const long long *__restrict__ recpre,
+                                                               int row_begin, int *__restrict__ tmp, int *__restrict__ cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    u32 *top = reinterpret_cast<u32 *>(lds_raw);                                // [topw] bit (c >> 5) of the column range
+    unsigned short *topPre = reinterpret_cast<unsigned short *>(top + topw);    // [topw] set bits of top before the word
+    u32 *S = top + topw + topw / 2;                                             // [kRankCap] slots; later the staged row
+    constexpr int kWaves = kRankThreads / 64;
+    __shared__ GatherLds<kRankThreads, kRankQPT> G;
+    __shared__ int wtot[kWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        u64 *z = reinterpret_cast<u64 *>(lds_raw);
+        const int nz = (topw * 6 + kRankCap * 4) / 8;
+        for (int t = tid; t < nz; t += kRankThreads) z[t] = 0ull;
+    }
+    gather_init(G);
+    __syncthreads();
+
+    const RowRec q = rec[blockIdx.x];
+    const int a0 = q.a0, a1 = q.a0 + q.alen;
+    int *out = tmp + recpre[blockIdx.x];
+
+    GatherState g;
+    // ---- sweep 1: the top bits ---------------------------------------------------------------------------------------
+    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, true, [&](const Int4U &v, u32 vm) {
+        const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
+        insert_quad(top, vm & 1u, vm & 2u, vm & 4u, vm & 8u, c0 >> 10, c1 >> 10, c2 >> 10, c3 >> 10,
+                    1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
+    });
+    // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) ---------------------------------------------
+    int nslots = 0;
+    {
+        const int WPT = topw / kRankThreads;                       // 1 or 2
+        u32 x[2];
+        int c[2], run = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            x[k] = k < WPT ? top[tid * WPT + k] : 0u;
+            c[k] = run;
+            run += __popc(x[k]);
+        }
+        const int inc = wave_incl_scan(run);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int off = 0;
+        for (int k = 0; k < kWaves; k++) {
+            const int t = wtot[k];
+            if (k < wave) off += t;
+            nslots += t;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (k < WPT) topPre[tid * WPT + k] = (unsigned short)(off + inc - run + c[k]);
+        __syncthreads();
+    }
+    // ---- sweep 2: bit (c & 31) of the slot whose index is the rank of top bit (c >> 5) --------------------------------
+    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, [&](const Int4U &v, u32 vm) {
+        const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
+        const bool i0 = vm & 1u, i1 = vm & 2u, i2 = vm & 4u, i3 = vm & 8u;
+        const u32 t0 = i0 ? c0 >> 10 : 0u, t1 = i1 ? c1 >> 10 : 0u, t2 = i2 ? c2 >> 10 : 0u, t3 = i3 ? c3 >> 10 : 0u;
+        const u32 x0 = top[t0], x1 = top[t1], x2 = top[t2], x3 = top[t3];
+        const u32 p0 = topPre[t0], p1 = topPre[t1], p2 = topPre[t2], p3 = topPre[t3];
+        const u32 r0 = p0 + __popc(__builtin_amdgcn_ubfe(x0, 0u, (c0 >> 5) & 31)), r1 = p1 + __popc(__builtin_amdgcn_ubfe(x1, 0u, (c1 >> 5) & 31));
+        const u32 r2 = p2 + __popc(__builtin_amdgcn_ubfe(x2, 0u, (c2 >> 5) & 31)), r3 = p3 + __popc(__builtin_amdgcn_ubfe(x3, 0u, (c3 >> 5) & 31));
+        // (r < kRankCap always on consistent operands: slots <= F_i <= kRankCap; a rewritten operand is cut off, not LDS overrun)
+        insert_quad(S, i0 && r0 < (u32)kRankCap, i1 && r1 < (u32)kRankCap, i2 && r2 < (u32)kRankCap, i3 && r3 < (u32)kRankCap, r0, r1, r2, r3,
+                    1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
+    });
+    // ---- read-out: slots are in column order.  Thread t owns the slots [t*SPT, (t+1)*SPT): their masks go to registers,
+    // one block scan gives the thread its place in the row, the top word of its first slot is found by binary search in
+    // the ranks and the others by walking the top bits; the columns are staged in LDS (over the slots, which every thread
+    // has read by then) and streamed out coalesced.
+    constexpr int SPT = kRankSlotsPerThread;
+    u32 m[SPT];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        m[k] = S[tid * SPT + k];
+        mine += __popc(m[k]);
+    }
+    const int inc = wave_incl_scan(mine);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int pos = inc - mine, total = 0;
+    for (int k = 0; k < kWaves; k++) {
+        const int t = wtot[k];
+        if (k < wave) pos += t;
+        total += t;
+    }
+    if (nslots > kRankCap) nslots = kRankCap;
+    const int s0 = tid * SPT;
+    if (s0 < nslots) {
+        int t = 0;                                                 // last top word whose rank is <= s0: it holds slot s0
+        for (int step = topw >> 1; step >= 1; step >>= 1)
+            if ((int)topPre[t + step] <= s0) t += step;
+        u32 rem = top[t];
+        for (int skip = s0 - (int)topPre[t]; skip > 0; skip--) rem &= rem - 1u;
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            if (s0 + k < nslots) {
+                while (!rem && t + 1 < topw) rem = top[++t];
+                const u32 base = ((u32)t << 10) | ((u32)__builtin_ctz(rem | 0x80000000u) << 5);
+                rem &= rem - 1u;
+                u32 mk = m[k];
+                while (mk) {
+                    if (pos < kRankCap) S[stage_swz(pos)] = base | (u32)__builtin_ctz(mk);   // (always, on consistent operands)
+                    pos++;
+                    mk &= mk - 1u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (total > q.f) total = q.f;                                  // (never, on consistent operands: the row's room is F_i <= kRankCap)
+    for (int t = tid; t < total; t += kRankThreads) __builtin_nontemporal_store((int)S[stage_swz(t)], out + t);
+    if (tid == 0) cnt[q.row - row_begin] = total;
+}
+
 template <bool MASKED, int THREADS>
 static hipError_t launch_dense_impl(const int2 *ab, const int *Bcol, long long nnzB, int cols, const RowRec *rec,
                                     const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt,
@@ -353,10 +525,33 @@ void launch_order_heavy(const RowRec *rec, const long long *recpre, int n, RowRe
     hipLaunchKernelGGL(k_order_heavy, dim3((n + 255) / 256), dim3(256), 0, s, rec, recpre, n, rec_out, pre_out);
 }
 
-hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, long long nnzB, int cols,
+// rows of the rank class are told apart by the prepass (bin_of): rank_cap_for_cols(cols) products or fewer
+int rank_cap_for_cols(long long cols)
+{
+    // (development switch, read once: BSPGEMM_RANK_ROWS=0 no rank class, =2 also where the small shape needs ONE window)
+    static const int mode = [] { const char *e = getenv("BSPGEMM_RANK_ROWS"); return e ? atoi(e) : 1; }();
+    if (mode <= 0 || cols > (1ll << 20)) return 0;                 // top bitmap + ranks + slots fill the small shape's 32 KiB up to 2^20 columns
+    if (mode == 1 && cols <= (1ll << 18)) return 0;
+    return kRankCap;
+}
+
+static hipError_t launch_rank_rows(const int2 *ab, const int *Bcol, long long nnzB, int cols, const RowRec *rec,
+                                   const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt, hipStream_t s)
+{
+    if (nrows <= 0) return hipSuccess;
+    const int topw = (int)((((long long)cols + 1023) >> 10) + kRankThreads - 1) / kRankThreads * kRankThreads;   // whole words per thread
+    const int bytes = topw * 6 + kRankCap * 4;
+    hipLaunchKernelGGL(k_rank_rows, dim3(nrows), dim3(kRankThreads), bytes, s, ab, Bcol,
+                       (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, topw, rec, recpre, row_begin, tmp, cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_rows(int bin, const int2 *ab, const int *Bcol, long long nnzB, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s)
 {
+    if (bin == kRankBin) return launch_rank_rows(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, s);
+    const bool mid = bin == kMidBin;
     if (mid)
         return launch_dense_impl<false, kDenseThreadsMid>(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);
     return launch_dense_impl<false, kDenseThreadsBig>(ab, Bcol, nnzB, cols, rec, recpre, nrows, row_begin, tmp, cnt, nullptr, nullptr, s);

@@ -76,7 +76,7 @@ struct bspgemm_context {
         hipEvent_t ev_cls[2][kNumBins][2] = {};     // per (phase, class): launch brackets
         int R = 0;
         bool cls_timed = false;                     // the class brackets of this multiply were recorded
-        int mid_cap = 0;
+        int mid_cap = 0, rank_cap = 0;
         HostScalars h = {};
         long long products = 0, nnz_c = 0;
         int cls_n[2][kNumBins] = {};

@@ -15,12 +15,17 @@ namespace bsp {
 //                straight-line over its CHUNKS 64-product chunks (exact s_waitcnt counts, no
 //                branches), so a row costs what its CLASS costs: the classes step by one chunk up
 //                to 512 products, by two up to 1024, then by four/eight
-//   kMidBin    : dense-window rows, 2048 < F_i <= mid_cap_for_cols(cols): 512-thread workgroups, four per CU
+//   kRankBin   : 2048 < F_i <= rank_cap_for_cols(cols) (0 = no such class for this column count): a 512-thread
+//                workgroup with a two-level rank bitmap -- LDS and read-out proportional to the row (dense_rows.hip)
+//   kMidBin    : dense-window rows, up to mid_cap_for_cols(cols) products: 512-thread workgroups, four per CU
 //   kDenseBin  : dense-window rows, above that: one 1024-thread workgroup per row
 constexpr int kWaveBins = 16;
-constexpr int kNumBins = kWaveBins + 3;
-constexpr int kMidBin = kWaveBins + 1;
-constexpr int kDenseBin = kWaveBins + 2;
+constexpr int kNumBins = kWaveBins + 4;
+constexpr int kRankBin = kWaveBins + 1;
+constexpr int kMidBin = kWaveBins + 2;
+constexpr int kDenseBin = kWaveBins + 3;
+constexpr int kRankCap = 6144;          // products (= slots) of a rank-class row
+int rank_cap_for_cols(long long cols);  // kRankCap, or 0 where the class is not used (dense_rows.hip)
 constexpr int kMaxBins = 20;            // size of the per-class arrays in bspgemm_stats
 constexpr int kWaveChunks[kWaveBins + 1] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
 constexpr int kMaxWaveCap = 64 * kWaveChunks[kWaveBins];   // 2048 products
@@ -115,7 +120,7 @@ struct PrepScalars {
 };
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int rank_cap, int bound_cols,
                          hipStream_t s, PrepScalars *scal = nullptr, const long long *true_F = nullptr);
 
 // prefix[0..n] = *base + exclusive scan of the int32 counts (base NULL = 0; may alias prefix[0])
@@ -148,7 +153,7 @@ void launch_place_heavy(const int *tmp, const RowRec *rec, const long long *recp
                         const long long *row_ptr, int row_begin, int *col_idx, hipStream_t s);
 
 // numeric phase, one workgroup per heavy row (windowed dense LDS bitmap); mid: the 512-thread shape
-hipError_t launch_dense_rows(bool mid, const int2 *ab, const int *Bcol, long long nnzB, int cols,
+hipError_t launch_dense_rows(int bin, const int2 *ab, const int *Bcol, long long nnzB, int cols,
                              const RowRec *rec, const long long *recpre, int nrows, int row_begin,
                              int *tmp, int *cnt, hipStream_t s);
 

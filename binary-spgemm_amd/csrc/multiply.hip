@@ -33,13 +33,14 @@ static void class_order(const int *bin_count, long long total_products, int *ord
     order[0] = 0;
     order[1] = kDenseBin;
     order[2] = kMidBin;
-    for (int pos = 3; pos < kNumBins; pos++) order[pos] = pos - 2;
-    const long long heavy_lower_bound = ((long long)bin_count[kMidBin] + bin_count[kDenseBin]) * kMaxWaveCap;
+    order[3] = kRankBin;
+    for (int pos = 4; pos < kNumBins; pos++) order[pos] = pos - 3;
+    const long long heavy_lower_bound = ((long long)bin_count[kRankBin] + bin_count[kMidBin] + bin_count[kDenseBin]) * kMaxWaveCap;
     if (heavy_lower_bound * 8 >= total_products) return;
     long long key[kNumBins] = {};
     for (int b = 1; b <= kWaveBins; b++) key[b] = (long long)bin_count[b] * kWaveChunks[b];
-    for (int a = 3; a < kNumBins; a++)                            // insertion sort of 16 entries, stable
-        for (int c = a; c > 3 && key[order[c]] > key[order[c - 1]]; c--) {
+    for (int a = 4; a < kNumBins; a++)                            // insertion sort of 16 entries, stable
+        for (int c = a; c > 4 && key[order[c]] > key[order[c - 1]]; c--) {
             const int t = order[c];
             order[c] = order[c - 1];
             order[c - 1] = t;
@@ -75,12 +76,13 @@ static bspgemm_status check_verdict(bspgemm_context *ctx)
 
 // closes the multiply's stat slot (its events have all completed: the caller has synchronised)
 static void close_slot(bspgemm_context *ctx, int R, const HostScalars *h, long long products, long long nnz_c,
-                       const int (*cls_n)[kNumBins], int mid_cap)
+                       const int (*cls_n)[kNumBins], int mid_cap, int rank_cap = 0)
 {
     bspgemm_context::StatSlot &sl = ctx->slots[ctx->slot_head];
     sl.R = R;
     sl.cls_timed = ctx->class_timing;
     sl.mid_cap = mid_cap;
+    sl.rank_cap = rank_cap;
     sl.h = *h;
     sl.products = products;
     sl.nnz_c = nnz_c;
@@ -138,7 +140,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
                     B->pad_state == 1 ? B->d_row_ptr_pad : nullptr, B->pad_state == 1 ? B->d_ext : nullptr, row_begin, row_end,
                     ctx->F, ctx->ab, s);
     launch_scan_and_bin(ctx->F, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
-                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), 0, s);
+                        ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, heavy_cols, ctx->hpartials, mid_cap_for_cols(B->cols), rank_cap_for_cols(B->cols), 0, s);
     HostScalars *h = ctx->h;
     HIPCHK_B(hipMemcpyAsync(&h->totalF, ctx->Fprefix + R, sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipMemcpyAsync(&h->heavy_total, ctx->hpartials + scan_tiles, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -191,7 +193,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             } else {
                 const long long *hpre = ctx->recpre + bin_start[b];
                 hub_order(ctx, b, n, rec, hpre, sx);
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->nnz, B->cols, rec, hpre, n,
+                HIPCHK_B(launch_dense_rows(b, ctx->ab, Bcol, B->nnz, B->cols, rec, hpre, n,
                                            row_begin, ctx->tmp, ctx->cnt, sx));
             }
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][1], sx));
@@ -254,7 +256,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     (void)synced;
     if (bspgemm_status st = check_verdict(ctx)) return bail(st);
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols));
+    close_slot(ctx, R, h, totalF, C->nnz, cls_n, mid_cap_for_cols(B->cols), rank_cap_for_cols(B->cols));
     *out = C;
     return BSPGEMM_OK;
 }
@@ -314,7 +316,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     }
     launch_scan_and_bin(size_by, R, row_begin, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles,
                         ctx->bin_count, ctx->rec, ctx->recpre, ctx->cnt, 0, ctx->hpartials, mid_cap_for_cols(B->cols),
-                        B->cols > 0 ? B->cols : 1, s, ctx->d_prep, Fm ? ctx->F : nullptr);
+                        Fm ? 0 : rank_cap_for_cols(B->cols), B->cols > 0 ? B->cols : 1, s, ctx->d_prep, Fm ? ctx->F : nullptr);
     HIPCHK_B(hipMemcpyAsync(&h->prep, ctx->d_prep, sizeof(PrepScalars), hipMemcpyDeviceToHost, s));
     HIPCHK_B(hipEventRecord(slot.ev[1], s));
     HIPCHK_B(hipStreamSynchronize(s));
@@ -360,7 +362,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
                 launch_wave_rows(b, levels, ctx->ab, Bcol, B->cols, rec, recpre, nullptr, n, row_begin,
                                  ctx->tmp, ctx->cnt, ctx->d_err, sx);
             else if (!Fm)
-                HIPCHK_B(launch_dense_rows(b == kMidBin, ctx->ab, Bcol, B->nnz, B->cols, rec, recpre, n, row_begin, ctx->tmp,
+                HIPCHK_B(launch_dense_rows(b, ctx->ab, Bcol, B->nnz, B->cols, rec, recpre, n, row_begin, ctx->tmp,
                                            ctx->cnt, sx));
             else if (b <= kWaveBins && wave_masked_supported(B->cols))
                 launch_wave_masked(b, ctx->ab, Bcol, B->cols, Fm->d_row_ptr, Fm->d_col_idx, rec, recpre, n,
@@ -397,7 +399,7 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
     HIPCHK_B(hipStreamSynchronize(s));
     if (bspgemm_status st = check_verdict(ctx)) return bail(st);
     C->nnz = h->nnzC;
-    close_slot(ctx, R, h, R > 0 ? h->products : 0, C->nnz, cls_n, mid_cap_for_cols(B->cols));
+    close_slot(ctx, R, h, R > 0 ? h->products : 0, C->nnz, cls_n, mid_cap_for_cols(B->cols), Fm ? 0 : rank_cap_for_cols(B->cols));
     *out = C;
     return BSPGEMM_OK;
 }
@@ -613,7 +615,7 @@ extern "C" bspgemm_status bspgemm_row_work_prefix(bspgemm_context *ctx, const bs
     if (bspgemm_status st = ensure_deg8(B)) return st;
     launch_row_products(A->d_row_ptr, A->d_col_idx, B->d_row_ptr, B->d_deg8, 0, R, ctx->F, ctx->stream);
     launch_scan_and_bin(ctx->F, R, 0, A->d_row_ptr, ctx->Fprefix, ctx->partials, ctx->bin_tiles, ctx->bin_count,
-                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), 0, ctx->stream);
+                        ctx->rec, ctx->recpre, ctx->cnt, 0, nullptr, mid_cap_for_cols(B->cols), rank_cap_for_cols(B->cols), 0, ctx->stream);
     HIPCHK(hipMemcpyAsync(prefix_host, ctx->Fprefix, ((size_t)R + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BSPGEMM_OK;

@@ -379,10 +379,10 @@ constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;   // 2048 values per workgroup
 
 // capacity class of a row with F products (see kernels.hpp)
-__device__ __forceinline__ int bin_of(long long F, int mid_cap)
+__device__ __forceinline__ int bin_of(long long F, int mid_cap, int rank_cap)
 {
     if (F <= 0) return 0;
-    if (F > kMaxWaveCap) return F > mid_cap ? kDenseBin : kMidBin;
+    if (F > kMaxWaveCap) return F <= rank_cap ? kRankBin : (F > mid_cap ? kDenseBin : kMidBin);
     const int f = (int)F;
     int b = 1;
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
                                                             long long *__restrict__ partials,
                                                             int *__restrict__ bin_tiles,
                                                             int heavy_cols, long long *__restrict__ hpartials,
-                                                            int mid_cap, int bound_cols,
+                                                            int mid_cap, int rank_cap, int bound_cols,
                                                             const long long *__restrict__ true_in,
                                                             long long *__restrict__ ppartials)
 {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kScanThreads) void k_tile_sums(const T *__restrict_
             v += (BIN && bound_cols > 0 && x > bound_cols) ? (long long)bound_cols : x;   // what is PLACED: |C_i| <= min(F_i, cols)
             if (BIN && ppartials) pv += true_in ? true_in[base + k] : x;                 // the products themselves
             if (BIN) {
-                const int b = bin_of(x, mid_cap);
+                const int b = bin_of(x, mid_cap, rank_cap);
                 atomicAdd(&lcount[b], 1);
                 if (b > kWaveBins) hv += x < heavy_cols ? x : heavy_cols;
             }
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                                                              const long long *carry_in,
                                                              int heavy_cols,
                                                              const long long *__restrict__ hpartials,
-                                                             int mid_cap, int bound_cols,
+                                                             int mid_cap, int rank_cap, int bound_cols,
                                                              PrepScalars *__restrict__ scal,
                                                              int *__restrict__ chunk_row)
 {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
                 if (off + pl[k] == total) chunk_row[(total + kCompactGran - 1) / kCompactGran] = base + k;
             }
             if (BIN) {
-                const int b = bin_of(v[k], mid_cap);
+                const int b = bin_of(v[k], mid_cap, rank_cap);
                 if (b == 0) {
                     cnt[base + k] = 0;
                 } else {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
 
 void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Arow, long long *prefix,
                          long long *partials, int *bin_tiles, int *bin_count, RowRec *rec,
-                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int bound_cols,
+                         long long *recpre, int *cnt, int heavy_cols, long long *hpartials, int mid_cap, int rank_cap, int bound_cols,
                          hipStream_t s, PrepScalars *scal, const long long *true_F)
 {
     if (n <= 0) {
@@ -630,12 +630,12 @@ void launch_scan_and_bin(const long long *F, int n, int row_begin, const int *Ar
     // without a heavy-row workspace hpartials[] is free: it carries the per-tile product counts
     const bool count_products = scal && heavy_cols <= 0;
     hipLaunchKernelGGL((k_tile_sums<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials, bin_tiles,
-                       heavy_cols, hpartials, mid_cap, bound_cols, true_F, count_products ? hpartials : nullptr);
+                       heavy_cols, hpartials, mid_cap, rank_cap, bound_cols, true_F, count_products ? hpartials : nullptr);
     hipLaunchKernelGGL(k_scan_partials, dim3(heavy_cols > 0 || count_products ? 2 + kNumBins : 1 + kNumBins), dim3(1024), 0,
                        s, partials, tiles, bin_tiles, bin_count, hpartials, count_products ? 1 : 0, scal);
     hipLaunchKernelGGL((k_scan_apply<long long, true>), dim3(tiles), dim3(kScanThreads), 0, s, F, n, partials,
                        prefix, row_begin, Arow, bin_tiles, bin_count, rec, recpre, cnt, nullptr, heavy_cols, hpartials,
-                       mid_cap, bound_cols, scal, nullptr);
+                       mid_cap, rank_cap, bound_cols, scal, nullptr);
 }
 
 // prefix[0..n] = base + exclusive scan of cnt[0..n); `base` (device, may be NULL = 0) may alias
@@ -648,10 +648,10 @@ void launch_scan_counts(const int *cnt, int n, long long *prefix, long long *par
         return;
     }
     const int tiles = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0, nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_sums<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partials, tiles, nullptr, nullptr, nullptr, 0, nullptr);
     hipLaunchKernelGGL((k_scan_apply<int, false>), dim3(tiles), dim3(kScanThreads), 0, s, cnt, n, partials, prefix,
-                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0, nullptr,
+                       0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, base, 0, nullptr, 0, 0, 0, nullptr,
                        base ? nullptr : chunk_row);
 }
 

@@ -158,8 +158,9 @@ def test_every_capacity_class_is_exercised(ctx):
     erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, n)
     crp, cci, st = hip_product(ctx, a_rp, a_ci, n, b_rp, b_ci, n)
     assert_same(crp, cci, erp, eci)
-    assert st["bin_cap"][1:-2] == caps and st["bins"] == len(caps) + 3, st["bin_cap"]
-    assert all(c > 0 for c in st["rows_per_bin"]), st["rows_per_bin"]
+    assert st["bin_cap"][1:-3] == caps and st["bins"] == len(caps) + 4, st["bin_cap"]
+    RANK = len(caps) + 1                                      # (the rank class is for 2^18 < cols <= 2^20: test_rank_rows_class)
+    assert all(c > 0 for k, c in enumerate(st["rows_per_bin"]) if k != RANK) and st["rows_per_bin"][RANK] == 0, st["rows_per_bin"]
 
 
 @pytest.mark.parametrize("ncols", [12_000_000, 40_000_000, 300_000_000],
@@ -193,6 +194,55 @@ def test_dense_rows_several_windows(ctx):
     crp, cci, st = hip_product(ctx, a_rp, a_ci, nb, b_rp, b_ci, ncols)
     assert_same(crp, cci, erp, eci)
     assert st["rows_per_bin"][-1] >= 2 and st["rows_per_bin"][-2] >= 1     # both heavy-row shapes, several windows each
+
+
+@pytest.mark.parametrize("ncols", [300_000, 700_001, 1 << 20], ids=["300k_one_top_word_per_thread", "700k", "2pow20"])
+def test_rank_rows_class(ctx, ncols):
+    """rows of 2048 < F_i <= 6144 products over two to four windows of the small heavy-row shape take the rank class
+    (csrc/dense_rows.hip k_rank_rows): boundaries of the class, dense column clusters (full 32-column slots, full top
+    words), sources of one to three entries (masked quads), more than 512 sources (several batches) and more than 4096
+    quads (several tiles), repeated A entries, the last column"""
+    rng = np.random.default_rng(ncols % 1000 + 77)
+    nb = 9000
+    lens = np.concatenate([rng.integers(1, 4, 6000), rng.integers(4, 200, 2000), rng.integers(200, 1500, 1000)])
+    rows, cols = [], []
+    for j, L in enumerate(lens):
+        kind = j % 4
+        if kind == 0:      # a dense cluster somewhere (consecutive columns: whole slots and top words)
+            c0 = int(rng.integers(0, ncols - L))
+            c = np.arange(c0, c0 + L)
+        elif kind == 1:    # the tail of the column range, including the last column
+            c = ncols - 1 - rng.choice(min(ncols, 4 * L + 8), size=L, replace=False)
+        else:
+            c = rng.choice(ncols, size=L, replace=False)
+        rows.append(np.full(L, j)); cols.append(c)
+    b_rp, b_ci = gen._csr_from_pairs(np.concatenate(rows), np.concatenate(cols), nb)
+    blen = np.diff(b_rp)
+    short = np.flatnonzero(blen <= 3); longer = np.flatnonzero(blen > 3)
+    a_rows, a_cols = [], []
+    targets = [2049, 2100, 3000, 4097, 5000, 6143, 6144, 6145, 7000, 2500, 2049, 6144, 5000]
+    ones = np.flatnonzero(blen == 1)
+    for i, t in enumerate(targets):
+        acc = 0
+        pool = short if i in (3, 4, 9) else longer            # rows 3, 4, 9: thousands of one-to-three-entry sources
+        if i == 12:
+            pool = ones                                       # 5000 one-entry sources: 5000 quads, two tiles of the gather plan
+        while acc < t:
+            j = int(pool[rng.integers(0, pool.size)])
+            if acc + blen[j] <= t:
+                a_rows.append(i); a_cols.append(j); acc += blen[j]
+            elif t - acc <= 3:
+                j = int(short[np.flatnonzero(blen[short] == t - acc)[0]])
+                a_rows.append(i); a_cols.append(j); acc += blen[j]
+    a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, len(targets), dedup=False)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+    crp, cci, st = hip_product(ctx, a_rp, a_ci, nb, b_rp, b_ci, ncols)
+    assert_same(crp, cci, erp, eci)
+    F = np.array([blen[a_ci[a_rp[i]:a_rp[i + 1]]].sum() for i in range(len(targets))])
+    assert list(F) == targets
+    RANK = st["bins"] - 3
+    assert st["bin_cap"][RANK] == 6144 and st["rows_per_bin"][RANK] == sum(1 for t in targets if t <= 6144), st["rows_per_bin"]
+    assert st["rows_per_bin"][RANK + 1] == sum(1 for t in targets if t > 6144)
 
 
 def test_fuzz_small_shapes(ctx):

@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r4q
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/r4q/pytest_quads.log 2>&1; echo pytest rc=$?; tail -3 gpurun_out/r4q/pytest_quads.log
-for w in g500 g500_20 powerlaw; do timeout -k 10 120 python3 tools/heavy_abl.py $w >> gpurun_out/r4q/quads2.log 2>&1 || echo "FAIL $w" >> gpurun_out/r4q/quads2.log; done
-grep -v amdgpu.ids gpurun_out/r4q/quads2.log
+for w in powerlaw g500; do timeout -k 10 200 python3 tools/bins.py $w 2>&1 | grep -v amdgpu | grep -E "nnzC|class 1[6-9]" ; done
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"

@@ -23,5 +23,7 @@ for i in range(3):
     C = ctx.multiply(A, A); nnz = C.nnz; C.free()
 st = ctx.stats()
 d = st["ms_bin"]; rows = st["rows_per_bin"]
-print("%-9s %-28s nnzC %11d numeric %7.3f  mid(17) %7.3f ms / %6d rows   hub(18) %7.3f ms / %5d rows" % (
-    which, os.path.basename(sys.argv[2]) if len(sys.argv) > 2 else "product", nnz, st["ms_numeric"], d[17], rows[17], d[18], rows[18]), flush=True)
+B = st["bins"]
+print("%-9s %-16s nnzC %11d numeric %7.3f  rank %7.3f ms / %6d rows  mid %7.3f ms / %6d rows   hub %7.3f ms / %5d rows" % (
+    which, os.path.basename(sys.argv[2]) if len(sys.argv) > 2 else "product", nnz, st["ms_numeric"], d[B - 3], rows[B - 3], d[B - 2], rows[B - 2],
+    d[B - 1], rows[B - 1]), flush=True)
