@@ -16,6 +16,9 @@
 // upper-bound-placed rows into C.col_idx.
 #include "kernels.hpp"
 #include "wave.hpp"
+#ifndef BSP_RANK_HOLD
+#define BSP_RANK_HOLD 1
+#endif
 #include <stdlib.h>
 
 namespace bsp {
@@ -184,7 +187,7 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kInFlight; u++) ins(cv[u], vmask[u]);
+                for (int u = 0; u < kInFlight; u++) ins(cv[u], vmask[u], u);
             }
         }
         __syncthreads();
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
     for (int win = 0; win < nwin; win++) {
         const long long lo = (long long)win * W;
         const int lo32 = (int)lo;
-        gather_sweep<kDenseThreads, kQPT, kInFlight>(G, g, ab, Bcol, nnzB, a0, a1, win == 0, [&](const Int4U &v, u32 vm) {
+        gather_sweep<kDenseThreads, kQPT, kInFlight>(G, g, ab, Bcol, nnzB, a0, a1, win == 0, [&](const Int4U &v, u32 vm, int) {
             const u32 c0 = (u32)(v.x - lo32), c1 = (u32)(v.y - lo32), c2 = (u32)(v.z - lo32), c3 = (u32)(v.w - lo32);
             insert_quad(bm32, (vm & 1u) && c0 < (u32)W, (vm & 2u) && c1 < (u32)W, (vm & 4u) && c2 < (u32)W, (vm & 8u) && c3 < (u32)W,   // (columns below the window wrap to huge values)
                         c0 >> 5, c1 >> 5, c2 >> 5, c3 >> 5, 1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
 // and ONE read-out proportional to the row, whatever the column count is -- the windowed shape runs one sweep and one
 // 4096-word read-out per 2^18 columns, four of each at 2^20 columns for a row that fills 1-2 % of every window, and
 // every one of them is a trip to memory that the row's eight waves wait for (profiles/r04_heavy_ablation.log).
-// LDS per workgroup: top (cols / 32 bits) + ranks (16 bits per top word) + kRankCap slots: 30 KiB at 2^20 columns,
+// LDS per workgroup: top (cols / 32 bits) + ranks (32 bits per top word) + kRankCap slots: 32 KiB at 2^20 columns,
 // beside the gather plan -- four workgroups per CU, as many as the windowed shape.
 constexpr int kRankThreads = 512;
 constexpr int kRankSlotsPerThread = kRankCap / kRankThreads;
@@ -359,17 +362,21 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
                                                                const long long *__restrict__ recpre,
                                                                int row_begin, int *__restrict__ tmp, int *__restrict__ cnt)
 {
+    // (the class is bound by LDS instruction issue -- profiles/r04_rank_rows_phases.log -- so the layout is chosen for few LDS
+    // instructions: a top word and its rank are one 8-byte pair, one read in sweep 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    u32 *top = reinterpret_cast<u32 *>(lds_raw);                                // [topw] bit (c >> 5) of the column range
-    unsigned short *topPre = reinterpret_cast<unsigned short *>(top + topw);    // [topw] set bits of top before the word
-    u32 *S = top + topw + topw / 2;                                             // [kRankCap] slots; later the staged row
+    uint2 *tp = reinterpret_cast<uint2 *>(lds_raw);                             // [topw] x: bit (c >> 5) of the column range, 32 per word; y: set bits before the word
+    u32 *tp32 = reinterpret_cast<u32 *>(lds_raw);
+    u32 *S = tp32 + 2 * topw;                                                   // [kRankCap] slots; later the staged row
     constexpr int kWaves = kRankThreads / 64;
+    constexpr int SPT = kRankSlotsPerThread;
     __shared__ GatherLds<kRankThreads, kRankQPT> G;
     __shared__ int wtot[kWaves];
+    __shared__ unsigned short fw[kRankThreads];                                 // top word that holds slot t * SPT
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         u64 *z = reinterpret_cast<u64 *>(lds_raw);
-        const int nz = (topw * 6 + kRankCap * 4) / 8;
+        const int nz = topw + kRankCap / 2;
         for (int t = tid; t < nz; t += kRankThreads) z[t] = 0ull;
     }
     gather_init(G);
@@ -380,12 +387,20 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     int *out = tmp + recpre[blockIdx.x];
 
     GatherState g;
+    // a row whose quads are one step of the gather keeps them in registers for the second sweep: no plan look-ups, no loads
+    Int4U hq[kRankInFlight];
+    u32 hm[kRankInFlight];
     // ---- sweep 1: the top bits ---------------------------------------------------------------------------------------
-    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, true, [&](const Int4U &v, u32 vm) {
+    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, true, [&](const Int4U &v, u32 vm, int u) {
+#if BSP_RANK_HOLD
+        hq[u] = v;
+        hm[u] = vm;
+#endif
         const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
-        insert_quad(top, vm & 1u, vm & 2u, vm & 4u, vm & 8u, c0 >> 10, c1 >> 10, c2 >> 10, c3 >> 10,
+        insert_quad(tp32, vm & 1u, vm & 2u, vm & 4u, vm & 8u, (c0 >> 10) * 2u, (c1 >> 10) * 2u, (c2 >> 10) * 2u, (c3 >> 10) * 2u,
                     1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
     });
+    const bool held = BSP_RANK_HOLD && g.plan_kept && g.QB <= kRankInFlight * kRankThreads;     // uniform
     // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) ---------------------------------------------
     int nslots = 0;
     {
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
         int c[2], run = 0;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            x[k] = k < WPT ? top[tid * WPT + k] : 0u;
+            x[k] = k < WPT ? tp[tid * WPT + k].x : 0u;
             c[k] = run;
             run += __popc(x[k]);
         }
@@ -409,27 +424,35 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
         }
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            if (k < WPT) topPre[tid * WPT + k] = (unsigned short)(off + inc - run + c[k]);
+            if (k < WPT) {
+                const int pre = off + inc - run + c[k], end = pre + __popc(x[k]);
+                tp[tid * WPT + k].y = (u32)pre;
+                for (int j = (pre + SPT - 1) / SPT; j * SPT < end && j < kRankThreads; j++) fw[j] = (unsigned short)(tid * WPT + k);   // (at most three)
+            }
         __syncthreads();
     }
     // ---- sweep 2: bit (c & 31) of the slot whose index is the rank of top bit (c >> 5) --------------------------------
-    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, [&](const Int4U &v, u32 vm) {
+    auto slot_bits = [&](const Int4U &v, u32 vm, int) {
         const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
         const bool i0 = vm & 1u, i1 = vm & 2u, i2 = vm & 4u, i3 = vm & 8u;
-        const u32 t0 = i0 ? c0 >> 10 : 0u, t1 = i1 ? c1 >> 10 : 0u, t2 = i2 ? c2 >> 10 : 0u, t3 = i3 ? c3 >> 10 : 0u;
-        const u32 x0 = top[t0], x1 = top[t1], x2 = top[t2], x3 = top[t3];
-        const u32 p0 = topPre[t0], p1 = topPre[t1], p2 = topPre[t2], p3 = topPre[t3];
-        const u32 r0 = p0 + __popc(__builtin_amdgcn_ubfe(x0, 0u, (c0 >> 5) & 31)), r1 = p1 + __popc(__builtin_amdgcn_ubfe(x1, 0u, (c1 >> 5) & 31));
-        const u32 r2 = p2 + __popc(__builtin_amdgcn_ubfe(x2, 0u, (c2 >> 5) & 31)), r3 = p3 + __popc(__builtin_amdgcn_ubfe(x3, 0u, (c3 >> 5) & 31));
+        const uint2 x0 = tp[i0 ? c0 >> 10 : 0u], x1 = tp[i1 ? c1 >> 10 : 0u], x2 = tp[i2 ? c2 >> 10 : 0u], x3 = tp[i3 ? c3 >> 10 : 0u];
+        const u32 r0 = x0.y + __popc(__builtin_amdgcn_ubfe(x0.x, 0u, (c0 >> 5) & 31)), r1 = x1.y + __popc(__builtin_amdgcn_ubfe(x1.x, 0u, (c1 >> 5) & 31));
+        const u32 r2 = x2.y + __popc(__builtin_amdgcn_ubfe(x2.x, 0u, (c2 >> 5) & 31)), r3 = x3.y + __popc(__builtin_amdgcn_ubfe(x3.x, 0u, (c3 >> 5) & 31));
         // (r < kRankCap always on consistent operands: slots <= F_i <= kRankCap; a rewritten operand is cut off, not LDS overrun)
         insert_quad(S, i0 && r0 < (u32)kRankCap, i1 && r1 < (u32)kRankCap, i2 && r2 < (u32)kRankCap, i3 && r3 < (u32)kRankCap, r0, r1, r2, r3,
                     1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
-    });
+    };
+    if (held) {
+#pragma unroll
+        for (int u = 0; u < kRankInFlight; u++) slot_bits(hq[u], hm[u], u);
+        __syncthreads();
+    } else {
+        gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, slot_bits);
+    }
     // ---- read-out: slots are in column order.  Thread t owns the slots [t*SPT, (t+1)*SPT): their masks go to registers,
-    // one block scan gives the thread its place in the row, the top word of its first slot is found by binary search in
-    // the ranks and the others by walking the top bits; the columns are staged in LDS (over the slots, which every thread
-    // has read by then) and streamed out coalesced.
-    constexpr int SPT = kRankSlotsPerThread;
+    // one block scan gives the thread its place in the row, the top word of its first slot was noted by the rank scan and
+    // the others follow by walking the top bits; the columns are staged in LDS (over the slots, which every thread has
+    // read by then) and streamed out coalesced.
     u32 m[SPT];
     int mine = 0;
 #pragma unroll
@@ -449,15 +472,14 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     if (nslots > kRankCap) nslots = kRankCap;
     const int s0 = tid * SPT;
     if (s0 < nslots) {
-        int t = 0;                                                 // last top word whose rank is <= s0: it holds slot s0
-        for (int step = topw >> 1; step >= 1; step >>= 1)
-            if ((int)topPre[t + step] <= s0) t += step;
-        u32 rem = top[t];
-        for (int skip = s0 - (int)topPre[t]; skip > 0; skip--) rem &= rem - 1u;
+        int t = fw[tid];
+        const uint2 first = tp[t];
+        u32 rem = first.x;
+        for (int skip = s0 - (int)first.y; skip > 0; skip--) rem &= rem - 1u;
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
             if (s0 + k < nslots) {
-                while (!rem && t + 1 < topw) rem = top[++t];
+                while (!rem && t + 1 < topw) rem = tp[++t].x;
                 const u32 base = ((u32)t << 10) | ((u32)__builtin_ctz(rem | 0x80000000u) << 5);
                 rem &= rem - 1u;
                 u32 mk = m[k];
@@ -540,7 +562,7 @@ static hipError_t launch_rank_rows(const int2 *ab, const int *Bcol, long long nn
 {
     if (nrows <= 0) return hipSuccess;
     const int topw = (int)((((long long)cols + 1023) >> 10) + kRankThreads - 1) / kRankThreads * kRankThreads;   // whole words per thread
-    const int bytes = topw * 6 + kRankCap * 4;
+    const int bytes = topw * 8 + kRankCap * 4;
     hipLaunchKernelGGL(k_rank_rows, dim3(nrows), dim3(kRankThreads), bytes, s, ab, Bcol,
                        (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, topw, rec, recpre, row_begin, tmp, cnt);
     return hipGetLastError();
