@@ -42,6 +42,7 @@ constexpr int kDenseInFlightBig = 8;         // 16-byte B.col_idx loads a thread
 constexpr int kDenseInFlightMid = 4;         //   (64 VGPRs)
 
 struct __attribute__((packed, aligned(4))) Int4U { int x, y, z, w; };   // 16 B, only dword aligned
+struct __attribute__((packed, aligned(4))) Int2U { int x, y; };
 
 // ---------------------------------------------------------------------------------------
 // The heavy rows' GATHER, shared by the windowed kernel and the rank kernel below: one sweep over all the products
@@ -96,12 +97,18 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
     constexpr int kWaves = LT::kWaves, kTileQ = LT::kTileQ, kTileWords = LT::kTileWords;
     static_assert(kQPT % kInFlight == 0, "whole steps");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (a row of several batches -- a hub row has thousands of sources -- loads the extents of batch j+1 while batch j is
+    // gathered: one trip to memory less per batch on the row's critical path, and a hub row has the CU to itself)
+    int2 e_next = make_int2(0, 0);
+    if (!g.plan_kept && a0 + tid < a1) e_next = ab[a0 + tid];
     for (int ja = a0; ja < a1; ja += kThreads) {
         int2 e = make_int2(0, 0);
         int nq = 0, cidx = 0;
         long long qexcl = 0;
         if (!g.plan_kept) {
-            if (ja + tid < a1) e = ab[ja + tid];
+            e = e_next;
+            e_next = make_int2(0, 0);
+            if (ja + kThreads + tid < a1) e_next = ab[ja + kThreads + tid];
             nq = (int)(((u32)e.y + 3u) >> 2);
             const int inc = wave_incl_scan(nq);
             const u64 nonempty = __ballot(nq > 0);
@@ -307,8 +314,34 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
             const int iw = wave_incl_scan(cw);
             const int step_total = wave_bcast(iw, 63);
             if (step_total == 0) continue;                     // uniform: an empty stretch of the window
-            int pos = run + iw - cw;
             const int base = (int)(lo + (long long)wl * 64);
+            // A step of few outputs is STAGED: the lanes expand their words into the step's own 2 KiB of the window (read and
+            // cleared just above, by this wave) and the wave streams the piece out coalesced.  Written straight from the
+            // per-lane loop, every store instruction of such a step touches up to 64 different 64-byte sectors -- those
+            // stores were 25-30 % of the small shape's time (profiles/r04_heavy_ablation.log, part 6).
+            const int stage_cap = 2 * ((wend - w0 < kStepWords) ? wend - w0 : kStepWords);    // 32-bit entries
+            if (step_total <= stage_cap) {                     // (uniform)
+                u32 *stage = reinterpret_cast<u32 *>(bm + w0);
+                int p = iw - cw;
+#pragma unroll
+                for (int k = 0; k < kWpl; k++) {
+                    u64 mk = m[k];
+                    while (mk) {
+                        stage[p++] = (u32)((base + 64 * k) | (int)__builtin_ctzll(mk));
+                        mk &= mk - 1ull;
+                    }
+                }
+                wave_lds_fence();
+                for (int j = lane; j < step_total; j += 64) {
+                    const u32 v = stage[j];
+                    stage[j] = 0u;                             // the window is all zero again
+                    out[run + j] = (int)v;
+                }
+                wave_lds_fence();
+                run += step_total;
+                continue;
+            }
+            int pos = run + iw - cw;
 #pragma unroll
             for (int k = 0; k < kWpl; k++) {
                 const int ck = __popcll(m[k]);
@@ -326,9 +359,19 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
                 }
                 u64 mk = (ck >= kDenseWordBits) ? 0ull : m[k];
                 int p = pos;
-                while (mk) {
-                    out[p++] = (base + 64 * k) | (int)__builtin_ctzll(mk);
+                while (mk) {                                   // two outputs per store instruction (8 bytes, only dword aligned)
+                    const int v0 = (base + 64 * k) | (int)__builtin_ctzll(mk);
                     mk &= mk - 1ull;
+                    if (mk) {
+                        Int2U v2;
+                        v2.x = v0;
+                        v2.y = (base + 64 * k) | (int)__builtin_ctzll(mk);
+                        mk &= mk - 1ull;
+                        *reinterpret_cast<Int2U *>(out + p) = v2;
+                        p += 2;
+                    } else {
+                        out[p++] = v0;
+                    }
                 }
                 pos += ck;
             }

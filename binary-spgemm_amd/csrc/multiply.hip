@@ -30,21 +30,28 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
 // classes queue behind them and ascending capacity measured better (power-law: +0.8 % otherwise): kept there.
 static void class_order(const int *bin_count, long long total_products, int *order)
 {
+    int light[kWaveBins];                                         // the one-wave classes in launch order
+    for (int k = 0; k < kWaveBins; k++) light[k] = k + 1;
+    const long long heavy_lower_bound = ((long long)bin_count[kRankBin] + bin_count[kMidBin] + bin_count[kDenseBin]) * kMaxWaveCap;
+    if (heavy_lower_bound * 8 < total_products) {
+        long long key[kNumBins] = {};
+        for (int b = 1; b <= kWaveBins; b++) key[b] = (long long)bin_count[b] * kWaveChunks[b];
+        for (int a = 1; a < kWaveBins; a++)                       // insertion sort of 16 entries, stable
+            for (int c = a; c > 0 && key[light[c]] > key[light[c - 1]]; c--) {
+                const int t = light[c];
+                light[c] = light[c - 1];
+                light[c - 1] = t;
+            }
+    }
+    // the rank class at position 4: with two class streams that is the stream of the small dense shape, not the one of the
+    // hub rows, which ends last where heavy rows matter (power-law stress input: it used to wait 2.5 ms for them)
     order[0] = 0;
     order[1] = kDenseBin;
     order[2] = kMidBin;
-    order[3] = kRankBin;
-    for (int pos = 4; pos < kNumBins; pos++) order[pos] = pos - 3;
-    const long long heavy_lower_bound = ((long long)bin_count[kRankBin] + bin_count[kMidBin] + bin_count[kDenseBin]) * kMaxWaveCap;
-    if (heavy_lower_bound * 8 >= total_products) return;
-    long long key[kNumBins] = {};
-    for (int b = 1; b <= kWaveBins; b++) key[b] = (long long)bin_count[b] * kWaveChunks[b];
-    for (int a = 4; a < kNumBins; a++)                            // insertion sort of 16 entries, stable
-        for (int c = a; c > 4 && key[order[c]] > key[order[c - 1]]; c--) {
-            const int t = order[c];
-            order[c] = order[c - 1];
-            order[c - 1] = t;
-        }
+    order[3] = light[0];
+    order[4] = kRankBin;
+    for (int k = 1; k < kWaveBins; k++) order[4 + k] = light[k];
+    static_assert(kNumBins == kWaveBins + 4, "every class has a position");
 }
 
 // the hub rows (class kDenseBin) of a multiply, largest first when there are few enough to rank
