@@ -16,9 +16,6 @@
 // upper-bound-placed rows into C.col_idx.
 #include "kernels.hpp"
 #include "wave.hpp"
-#ifndef BSP_RANK_HOLD
-#define BSP_RANK_HOLD 1
-#endif
 #include <stdlib.h>
 
 namespace bsp {
@@ -435,15 +432,13 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     u32 hm[kRankInFlight];
     // ---- sweep 1: the top bits ---------------------------------------------------------------------------------------
     gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, true, [&](const Int4U &v, u32 vm, int u) {
-#if BSP_RANK_HOLD
         hq[u] = v;
         hm[u] = vm;
-#endif
         const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
         insert_quad(tp32, vm & 1u, vm & 2u, vm & 4u, vm & 8u, (c0 >> 10) * 2u, (c1 >> 10) * 2u, (c2 >> 10) * 2u, (c3 >> 10) * 2u,
                     1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
     });
-    const bool held = BSP_RANK_HOLD && g.plan_kept && g.QB <= kRankInFlight * kRankThreads;     // uniform
+    const bool held = g.plan_kept && g.QB <= kRankInFlight * kRankThreads;     // uniform
     // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) ---------------------------------------------
     int nslots = 0;
     {

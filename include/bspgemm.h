@@ -67,7 +67,8 @@ const char *bspgemm_build_info(void);
  * Environment (read once, in bspgemm_create; every knob also has a setter, bspgemm_set_option / _set_flow /
  * _set_class_timing, which is what a running program uses): BSPGEMM_FLOW=auto|upper-bound|exact,
  * BSPGEMM_CLASS_STREAMS=1..3, BSPGEMM_CLASS_TIMING=0|1, BSPGEMM_RW_BLK=0|1, BSPGEMM_CHECK, BSPGEMM_SMALL=0|1, BSPGEMM_PAD_ROWS=0|1,
- * BSPGEMM_DEBUG_ALLOC, BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.          */
+ * BSPGEMM_DEBUG_ALLOC, BSPGEMM_DROPIN_TIMING; BSPGEMM_DEVICE picks the drop-ins' device.  (BSPGEMM_RANK_ROWS=0|1|2 is a
+ * development switch of the rank class, read once per process: 0 none, 1 default, 2 also for single-window column counts.)        */
 typedef struct bspgemm_context bspgemm_context;   /* one per GPU: device, stream, workspaces  */
 typedef struct bspgemm_matrix  bspgemm_matrix;    /* device-resident CSR operand, int32 row_ptr */
 typedef struct bspgemm_result  bspgemm_result;    /* device-resident CSR product, int64 row_ptr */
@@ -219,9 +220,11 @@ typedef struct bspgemm_stats {
     int64_t bytes_alg;       /* 4(rows+1)+4nnzA+8nnzA+4F+4nnzC+8(rows+1)     */
     int64_t bytes_read_alg;  /* its HBM-read part: bytes_alg - 4nnzC - 8(rows+1)             */
     int64_t rows_per_bin[BSPGEMM_MAX_BINS]; /* rows per capacity class: [0] empty rows,
-                                [1..bins-3] one-wavefront rows with at most bin_cap[b] products,
-                                [bins-2], [bins-1] heavy rows (one 512- / 1024-thread workgroup
-                                each); rest unused                                           */
+                                [1..bins-4] one-wavefront rows with at most bin_cap[b] products,
+                                [bins-3] rank rows (2048 < products <= bin_cap: one 512-thread
+                                workgroup with a rank bitmap; bin_cap = 2048 where the class is
+                                not used), [bins-2], [bins-1] heavy rows (one 512- / 1024-thread
+                                workgroup each over dense column windows); rest unused        */
     float   ms_total;        /* hipEvent time of the whole multiply on the stream            */
     float   ms_symbolic;     /* = ms_prepass + ms_count: everything that sizes C.row_ptr     */
     float   ms_prepass;      /*   row work (products per row) + scan + capacity classes      */
