@@ -14,7 +14,7 @@ rng = np.random.default_rng(77)
 ctx = bspgemm.Context(0)
 t0 = time.perf_counter()
 for k in range(cases):
-    kind = k % 5
+    kind = k % 6
     ctx.set_flow(("upper-bound", "exact", "auto")[(k // 5) % 3])
     # round 4: the per-operand paths in rotation as well (decided when an operand is first used as B: fresh operands per case)
     ctx.set_option("padded_rows", (0, 1, -1)[(k // 3) % 3])
@@ -27,6 +27,11 @@ for k in range(cases):
     elif kind == 1:
         n = int(rng.integers(5_000, 120_000))
         rp, ci, n = bspgemm.gen_powerlaw(n, int(rng.integers(4, 40)), seed=2000 + k)
+        b_rp, b_ci, ncols = rp, ci, n
+    elif kind == 5:
+        # round 4: 2^18 < cols <= 2^20 with skew -- rows of 2-6 K products take the rank class (k_rank_rows), larger ones two to four windows
+        sc = int(rng.integers(19, 21)); abc = [(0.45, 0.22, 0.22), (0.57, 0.19, 0.19), (0.50, 0.20, 0.20)][k // 6 % 3]
+        rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(2, 5)), abc, seed=5000 + k)
         b_rp, b_ci, ncols = rp, ci, n
     elif kind == 2:
         n = int(rng.integers(1_000, 300_000))
@@ -60,8 +65,10 @@ for k in range(cases):
             frp, fci = O.spgemm_masked(rp, ci, b_rp, b_ci, ncols, rp, ci)
             mok = np.array_equal(mrp, frp) and np.array_equal(mci, fci)
             M.free()
-    print("case %2d %-11s pad %d blk %d small %d kind %d rows %7d cols %9d products %.3g nnz %.3g  %s %s" %
+    B_ = st["bins"]
+    print("case %2d %-11s pad %d blk %d small %d kind %d rows %7d cols %9d products %.3g nnz %.3g heavy rows %d/%d/%d  %s %s" %
           (k, ("upper-bound", "exact", "auto")[(k // 5) % 3], st["padded_rows"], st["prepass_kernel"], st["small_path"], kind, n, ncols, st["products"], erp[-1],
+           st["rows_per_bin"][B_ - 3], st["rows_per_bin"][B_ - 2], st["rows_per_bin"][B_ - 1],
            "OK" if ok else "MISMATCH", "" if mok else "MASKED MISMATCH"), flush=True)
     C.free()
     if B is not A:
