@@ -48,9 +48,14 @@ static void class_order(const int *bin_count, long long total_products, int *ord
     order[0] = 0;
     order[1] = kDenseBin;
     order[2] = kMidBin;
-    order[3] = light[0];
-    order[4] = kRankBin;
-    for (int k = 1; k < kWaveBins; k++) order[4 + k] = light[k];
+    if (bin_count[kRankBin] > 0) {
+        order[3] = light[0];
+        order[4] = kRankBin;
+        for (int k = 1; k < kWaveBins; k++) order[4 + k] = light[k];
+    } else {                                                      // (no such rows: the one-wave classes alternate over the streams as they always did)
+        for (int k = 0; k < kWaveBins; k++) order[3 + k] = light[k];
+        order[3 + kWaveBins] = kRankBin;
+    }
     static_assert(kNumBins == kWaveBins + 4, "every class has a position");
 }
 
