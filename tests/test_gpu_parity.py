@@ -245,6 +245,27 @@ def test_rank_rows_class(ctx, ncols):
     assert st["rows_per_bin"][RANK + 1] == sum(1 for t in targets if t > 6144)
 
 
+@pytest.mark.parametrize("nnzb", [1, 2, 3, 5])
+def test_heavy_row_over_a_tiny_b(ctx, nnzb):
+    """the heavy rows gather B in 16-byte quads; a B.col_idx of fewer than four entries has no room for one (scalar loads),
+    and the quads of the first sources of a B begin before the array (clamped and masked): a row of 3000-5000 repeated A entries
+    over a B of 1, 2, 3 and 5 nonzeros"""
+    ncols = 11
+    b_rows = [0, 1, 1, 2, 2][:nnzb]
+    b_cols = [7, 0, 10, 3, 4][:nnzb]
+    b_rp, b_ci = gen._csr_from_pairs(b_rows, b_cols, 3)
+    rng = np.random.default_rng(900 + nnzb)
+    nrep = 5000
+    a_rows = np.concatenate([np.zeros(nrep, np.int64), np.ones(3, np.int64)])
+    a_cols = np.concatenate([rng.integers(0, 3, size=nrep), [0, 1, 2]])
+    a_rp, a_ci = gen._csr_from_pairs(a_rows, a_cols, 2, dedup=False)
+    erp, eci = O.spgemm(a_rp, a_ci, b_rp, b_ci, ncols)
+    crp, cci, st = hip_product(ctx, a_rp, a_ci, 3, b_rp, b_ci, ncols)
+    assert_same(crp, cci, erp, eci)
+    if nnzb >= 2:
+        assert sum(st["rows_per_bin"][-3:]) == 1, st["rows_per_bin"]      # row 0 is a heavy row (F > 2048)
+
+
 def test_fuzz_small_shapes(ctx):
     """150 seeded random shapes against the oracle: rectangular, skewed, duplicate-heavy, column
     counts on every side of the level boundaries (8192, 2^18, 2^23, 2^24), row ranges, masks"""
