@@ -1,17 +1,16 @@
-// dense_rows.hip -- heavy rows (F_i > 2048 products): one 1024-thread workgroup per A-row with
-// a dense column bitmap held in LDS, swept over column windows of up to 2^20 bits (128 KiB).
+// dense_rows.hip -- heavy rows (F_i > 2048 products), one workgroup per A-row, three kernels over ONE gather:
 //
-// This is the literal GPU form of the reference's accumulator (final/SpGEMM_mpi_omp.c:21,38-42):
-// xb[k] becomes bit k of the LDS bitmap, test-and-set becomes ds_or_b32, and the quickSort of
-// the row (:47) disappears because the bitmap is read out in column order.  Rows this heavy have
-// many duplicate products, so the result is dense enough that scanning the window pays.
-// Gather: the row's A-nonzeros are taken one per thread at a time; their B-row extents (left by the
-// prepass) are scanned into product offsets, and the batch's products are spread evenly over the
-// threads in tiles -- thread t takes products t, t+T, ... of a tile and finds each one's source row
-// by rank in a per-tile "starts" bitmap (the wave kernels' gather plan at workgroup scope) -- eight
-// independent loads in flight per thread, whatever the B-row lengths are.
-// When cols > 2^20 the row's products are re-gathered once per window (B is L2/MALL resident
-// for a hub row: its B rows were just read by the previous window).
+//   k_dense_rows   a dense column bitmap in LDS, swept over column windows: the literal GPU form of the reference's accumulator
+//                  (final/SpGEMM_mpi_omp.c:21,38-42) -- xb[k] becomes bit k of the LDS bitmap, test-and-set becomes ds_or_b32, and
+//                  the quickSort of the row (:47) disappears because the bitmap is read out in column order.  Two shapes: 1024
+//                  threads over windows of up to 2^20 columns (128 KiB), 512 threads over 2^18 (32 KiB).  When the columns exceed the
+//                  window the row's products are gathered once per window;
+//   k_rank_rows    (round 4) rows of at most 6144 products where the small shape would need two to four windows: a two-level rank
+//                  bitmap sized by the ROW -- two sweeps and one read-out whatever the column count (see the kernel);
+//   gather_sweep   the row's A-nonzeros one per thread; their B-row extents (left by the prepass) are scanned into QUAD offsets -- a
+//                  quad is four consecutive entries of one B row, one 16-byte load -- and the quads are spread evenly over the
+//                  threads in tiles: thread t takes quads t, t+T, ... and finds each one's source row by rank in a per-tile "starts"
+//                  bitmap (the wave kernels' gather plan at workgroup scope), whatever the B-row lengths are.
 // Also holds the exact flow's move of the heavy rows (k_place_heavy) and the compaction kernel that squeezes the
 // upper-bound-placed rows into C.col_idx.
 #include "kernels.hpp"
