@@ -394,7 +394,9 @@ constexpr int kRankThreads = 512;
 constexpr int kRankSlotsPerThread = kRankCap / kRankThreads;
 static_assert(kRankCap % kRankThreads == 0, "whole slots per thread");
 constexpr int kRankQPT = 8, kRankInFlight = 4;
+constexpr int kRankSpan = 1 << 20;           // columns one pass covers: the top bitmap's reach (4 KiB of top bits)
 
+template <bool kSpans>   // false: the column range is one span (the common case: one pass, its quads kept in registers)
 __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__restrict__ ab, const int *__restrict__ Bcol, int nnzB,
                                                                int cols, int topw,
                                                                const RowRec *__restrict__ rec,
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     // (the class is bound by LDS instruction issue -- profiles/r04_rank_rows_phases.log -- so the layout is chosen for few LDS
     // instructions: a top word and its rank are one 8-byte pair, one read in sweep 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint2 *tp = reinterpret_cast<uint2 *>(lds_raw);                             // [topw] x: bit (c >> 5) of the column range, 32 per word; y: set bits before the word
+    uint2 *tp = reinterpret_cast<uint2 *>(lds_raw);                             // [topw] x: bit (c >> 5) of the span, 32 per word; y: set bits before the word
     u32 *tp32 = reinterpret_cast<u32 *>(lds_raw);
     u32 *S = tp32 + 2 * topw;                                                   // [kRankCap] slots; later the staged row
     constexpr int kWaves = kRankThreads / 64;
@@ -413,10 +415,10 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     __shared__ int wtot[kWaves];
     __shared__ unsigned short fw[kRankThreads];                                 // top word that holds slot t * SPT
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nclear = topw + kRankCap / 2;                                     // 8-byte words of the accumulator
     {
         u64 *z = reinterpret_cast<u64 *>(lds_raw);
-        const int nz = topw + kRankCap / 2;
-        for (int t = tid; t < nz; t += kRankThreads) z[t] = 0ull;
+        for (int t = tid; t < nclear; t += kRankThreads) z[t] = 0ull;
     }
     gather_init(G);
     __syncthreads();
@@ -426,111 +428,131 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     int *out = tmp + recpre[blockIdx.x];
 
     GatherState g;
-    // a row whose quads are one step of the gather keeps them in registers for the second sweep: no plan look-ups, no loads
+    // a row whose quads are one step of the gather keeps them in registers for every later sweep: no plan look-ups, no loads
     Int4U hq[kRankInFlight];
     u32 hm[kRankInFlight];
-    // ---- sweep 1: the top bits ---------------------------------------------------------------------------------------
-    gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, true, [&](const Int4U &v, u32 vm, int u) {
-        hq[u] = v;
-        hm[u] = vm;
-        const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
-        insert_quad(tp32, vm & 1u, vm & 2u, vm & 4u, vm & 8u, (c0 >> 10) * 2u, (c1 >> 10) * 2u, (c2 >> 10) * 2u, (c3 >> 10) * 2u,
-                    1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
-    });
-    const bool held = g.plan_kept && g.QB <= kRankInFlight * kRankThreads;     // uniform
-    // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) ---------------------------------------------
-    int nslots = 0;
-    {
-        const int WPT = topw / kRankThreads;                       // 1 or 2
-        u32 x[2];
-        int c[2], run = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            x[k] = k < WPT ? tp[tid * WPT + k].x : 0u;
-            c[k] = run;
-            run += __popc(x[k]);
-        }
-        const int inc = wave_incl_scan(run);
-        if (lane == 63) wtot[wave] = inc;
-        __syncthreads();
-        int off = 0;
-        for (int k = 0; k < kWaves; k++) {
-            const int t = wtot[k];
-            if (k < wave) off += t;
-            nslots += t;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (k < WPT) {
-                const int pre = off + inc - run + c[k], end = pre + __popc(x[k]);
-                tp[tid * WPT + k].y = (u32)pre;
-                for (int j = (pre + SPT - 1) / SPT; j * SPT < end && j < kRankThreads; j++) fw[j] = (unsigned short)(tid * WPT + k);   // (at most three)
+    bool held = false;                                             // uniform
+    // The column range is taken in SPANS of 2^20 columns (the top bitmap's reach): one for the matrices the class was built
+    // for, up to sixteen on wider ones -- where the small dense shape would sweep and read out 4 * sixteen windows.
+    const int nspans = kSpans ? (int)(((long long)cols + kRankSpan - 1) / kRankSpan) : 1;
+    int total = 0;
+    for (int sp = 0; sp < nspans; sp++) {
+        const u32 lo = kSpans ? (u32)sp * (u32)kRankSpan : 0u;
+        // ---- sweep 1: the top bits -----------------------------------------------------------------------------------
+        auto top_bits = [&](const Int4U &v, u32 vm, int u) {
+            if (!kSpans) {
+                hq[u] = v;
+                hm[u] = vm;
             }
-        __syncthreads();
-    }
-    // ---- sweep 2: bit (c & 31) of the slot whose index is the rank of top bit (c >> 5) --------------------------------
-    auto slot_bits = [&](const Int4U &v, u32 vm, int) {
-        const u32 c0 = (u32)v.x, c1 = (u32)v.y, c2 = (u32)v.z, c3 = (u32)v.w;
-        const bool i0 = vm & 1u, i1 = vm & 2u, i2 = vm & 4u, i3 = vm & 8u;
-        const uint2 x0 = tp[i0 ? c0 >> 10 : 0u], x1 = tp[i1 ? c1 >> 10 : 0u], x2 = tp[i2 ? c2 >> 10 : 0u], x3 = tp[i3 ? c3 >> 10 : 0u];
-        const u32 r0 = x0.y + __popc(__builtin_amdgcn_ubfe(x0.x, 0u, (c0 >> 5) & 31)), r1 = x1.y + __popc(__builtin_amdgcn_ubfe(x1.x, 0u, (c1 >> 5) & 31));
-        const u32 r2 = x2.y + __popc(__builtin_amdgcn_ubfe(x2.x, 0u, (c2 >> 5) & 31)), r3 = x3.y + __popc(__builtin_amdgcn_ubfe(x3.x, 0u, (c3 >> 5) & 31));
-        // (r < kRankCap always on consistent operands: slots <= F_i <= kRankCap; a rewritten operand is cut off, not LDS overrun)
-        insert_quad(S, i0 && r0 < (u32)kRankCap, i1 && r1 < (u32)kRankCap, i2 && r2 < (u32)kRankCap, i3 && r3 < (u32)kRankCap, r0, r1, r2, r3,
-                    1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
-    };
-    if (held) {
+            const u32 c0 = (u32)v.x - lo, c1 = (u32)v.y - lo, c2 = (u32)v.z - lo, c3 = (u32)v.w - lo;   // (columns below the span wrap to huge values)
+            insert_quad(tp32, (vm & 1u) && (!kSpans || c0 < (u32)kRankSpan), (vm & 2u) && (!kSpans || c1 < (u32)kRankSpan),
+                        (vm & 4u) && (!kSpans || c2 < (u32)kRankSpan), (vm & 8u) && (!kSpans || c3 < (u32)kRankSpan), (c0 >> 10) * 2u, (c1 >> 10) * 2u, (c2 >> 10) * 2u, (c3 >> 10) * 2u,
+                        1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
+        };
+        gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, sp == 0, top_bits);
+        if (!kSpans) held = g.plan_kept && g.QB <= kRankInFlight * kRankThreads;   // (only ever used by sweep 2 of the single span)
+        // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) -----------------------------------------
+        int nslots = 0;
+        {
+            const int WPT = topw / kRankThreads;                   // 1 or 2
+            u32 x[2];
+            int c[2], run = 0;
 #pragma unroll
-        for (int u = 0; u < kRankInFlight; u++) slot_bits(hq[u], hm[u], u);
-        __syncthreads();
-    } else {
-        gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, slot_bits);
-    }
-    // ---- read-out: slots are in column order.  Thread t owns the slots [t*SPT, (t+1)*SPT): their masks go to registers,
-    // one block scan gives the thread its place in the row, the top word of its first slot was noted by the rank scan and
-    // the others follow by walking the top bits; the columns are staged in LDS (over the slots, which every thread has
-    // read by then) and streamed out coalesced.
-    u32 m[SPT];
-    int mine = 0;
+            for (int k = 0; k < 2; k++) {
+                x[k] = k < WPT ? tp[tid * WPT + k].x : 0u;
+                c[k] = run;
+                run += __popc(x[k]);
+            }
+            const int inc = wave_incl_scan(run);
+            if (lane == 63) wtot[wave] = inc;
+            __syncthreads();
+            int off = 0;
+            for (int k = 0; k < kWaves; k++) {
+                const int t = wtot[k];
+                if (k < wave) off += t;
+                nslots += t;
+            }
 #pragma unroll
-    for (int k = 0; k < SPT; k++) {
-        m[k] = S[tid * SPT + k];
-        mine += __popc(m[k]);
-    }
-    const int inc = wave_incl_scan(mine);
-    if (lane == 63) wtot[wave] = inc;
-    __syncthreads();
-    int pos = inc - mine, total = 0;
-    for (int k = 0; k < kWaves; k++) {
-        const int t = wtot[k];
-        if (k < wave) pos += t;
-        total += t;
-    }
-    if (nslots > kRankCap) nslots = kRankCap;
-    const int s0 = tid * SPT;
-    if (s0 < nslots) {
-        int t = fw[tid];
-        const uint2 first = tp[t];
-        u32 rem = first.x;
-        for (int skip = s0 - (int)first.y; skip > 0; skip--) rem &= rem - 1u;
+            for (int k = 0; k < 2; k++)
+                if (k < WPT) {
+                    const int pre = off + inc - run + c[k], end = pre + __popc(x[k]);
+                    tp[tid * WPT + k].y = (u32)pre;
+                    for (int j = (pre + SPT - 1) / SPT; j * SPT < end && j < kRankThreads; j++) fw[j] = (unsigned short)(tid * WPT + k);   // (at most three)
+                }
+            __syncthreads();
+        }
+        // ---- sweep 2: bit (c & 31) of the slot whose index is the rank of top bit (c >> 5) ----------------------------
+        auto slot_bits = [&](const Int4U &v, u32 vm, int) {
+            const u32 c0 = (u32)v.x - lo, c1 = (u32)v.y - lo, c2 = (u32)v.z - lo, c3 = (u32)v.w - lo;
+            const bool i0 = (vm & 1u) && (!kSpans || c0 < (u32)kRankSpan), i1 = (vm & 2u) && (!kSpans || c1 < (u32)kRankSpan);
+            const bool i2 = (vm & 4u) && (!kSpans || c2 < (u32)kRankSpan), i3 = (vm & 8u) && (!kSpans || c3 < (u32)kRankSpan);
+            const uint2 x0 = tp[i0 ? c0 >> 10 : 0u], x1 = tp[i1 ? c1 >> 10 : 0u], x2 = tp[i2 ? c2 >> 10 : 0u], x3 = tp[i3 ? c3 >> 10 : 0u];
+            const u32 r0 = x0.y + __popc(__builtin_amdgcn_ubfe(x0.x, 0u, (c0 >> 5) & 31)), r1 = x1.y + __popc(__builtin_amdgcn_ubfe(x1.x, 0u, (c1 >> 5) & 31));
+            const u32 r2 = x2.y + __popc(__builtin_amdgcn_ubfe(x2.x, 0u, (c2 >> 5) & 31)), r3 = x3.y + __popc(__builtin_amdgcn_ubfe(x3.x, 0u, (c3 >> 5) & 31));
+            // (r < kRankCap always on consistent operands: slots <= F_i <= kRankCap; a rewritten operand is cut off, not LDS overrun)
+            insert_quad(S, i0 && r0 < (u32)kRankCap, i1 && r1 < (u32)kRankCap, i2 && r2 < (u32)kRankCap, i3 && r3 < (u32)kRankCap, r0, r1, r2, r3,
+                        1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
+        };
+        if (held) {
+#pragma unroll
+            for (int u = 0; u < kRankInFlight; u++) slot_bits(hq[u], hm[u], u);
+            __syncthreads();
+        } else {
+            gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, slot_bits);
+        }
+        // ---- read-out: slots are in column order.  Thread t owns the slots [t*SPT, (t+1)*SPT): their masks go to registers,
+        // one block scan gives the thread its place in the row, the top word of its first slot was noted by the rank scan and
+        // the others follow by walking the top bits; the columns are staged in LDS (over the slots, which every thread has
+        // read by then) and streamed out coalesced.
+        u32 m[SPT];
+        int mine = 0;
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            if (s0 + k < nslots) {
-                while (!rem && t + 1 < topw) rem = tp[++t].x;
-                const u32 base = ((u32)t << 10) | ((u32)__builtin_ctz(rem | 0x80000000u) << 5);
-                rem &= rem - 1u;
-                u32 mk = m[k];
-                while (mk) {
-                    if (pos < kRankCap) S[stage_swz(pos)] = base | (u32)__builtin_ctz(mk);   // (always, on consistent operands)
-                    pos++;
-                    mk &= mk - 1u;
+            m[k] = S[tid * SPT + k];
+            mine += __popc(m[k]);
+        }
+        const int inc = wave_incl_scan(mine);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int pos = inc - mine, stotal = 0;
+        for (int k = 0; k < kWaves; k++) {
+            const int t = wtot[k];
+            if (k < wave) pos += t;
+            stotal += t;
+        }
+        if (nslots > kRankCap) nslots = kRankCap;
+        const int s0 = tid * SPT;
+        if (s0 < nslots) {
+            int t = fw[tid];
+            const uint2 first = tp[t];
+            u32 rem = first.x;
+            for (int skip = s0 - (int)first.y; skip > 0; skip--) rem &= rem - 1u;
+#pragma unroll
+            for (int k = 0; k < SPT; k++) {
+                if (s0 + k < nslots) {
+                    while (!rem && t + 1 < topw) rem = tp[++t].x;
+                    const u32 base = lo + (((u32)t << 10) | ((u32)__builtin_ctz(rem | 0x80000000u) << 5));
+                    rem &= rem - 1u;
+                    u32 mk = m[k];
+                    while (mk) {
+                        if (pos < kRankCap) S[stage_swz(pos)] = base | (u32)__builtin_ctz(mk);   // (always, on consistent operands)
+                        pos++;
+                        mk &= mk - 1u;
+                    }
                 }
             }
         }
+        __syncthreads();
+        if (total + stotal > q.f) stotal = q.f > total ? q.f - total : 0;          // (never, on consistent operands: the row's room is F_i <= kRankCap)
+        for (int t = tid; t < stotal; t += kRankThreads) __builtin_nontemporal_store((int)S[stage_swz(t)], out + total + t);
+        total += stotal;
+        if (sp + 1 < nspans) {                                     // the accumulator all zero again for the next span
+            __syncthreads();
+            u64 *z = reinterpret_cast<u64 *>(lds_raw);
+            for (int t = tid; t < nclear; t += kRankThreads) z[t] = 0ull;
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    if (total > q.f) total = q.f;                                  // (never, on consistent operands: the row's room is F_i <= kRankCap)
-    for (int t = tid; t < total; t += kRankThreads) __builtin_nontemporal_store((int)S[stage_swz(t)], out + t);
     if (tid == 0) cnt[q.row - row_begin] = total;
 }
 
@@ -589,7 +611,7 @@ int rank_cap_for_cols(long long cols)
 {
     // (development switch, read once: BSPGEMM_RANK_ROWS=0 no rank class, =2 also where the small shape needs ONE window)
     static const int mode = [] { const char *e = getenv("BSPGEMM_RANK_ROWS"); return e ? atoi(e) : 1; }();
-    if (mode <= 0 || cols > (1ll << 20)) return 0;                 // top bitmap + ranks + slots fill the small shape's 32 KiB up to 2^20 columns
+    if (mode <= 0 || cols > (1ll << 24)) return 0;                 // (one pass per 2^20 columns: sixteen at most; wider matrices keep the dense shapes)
     if (mode == 1 && cols <= (1ll << 18)) return 0;
     return kRankCap;
 }
@@ -598,10 +620,15 @@ static hipError_t launch_rank_rows(const int2 *ab, const int *Bcol, long long nn
                                    const long long *recpre, int nrows, int row_begin, int *tmp, int *cnt, hipStream_t s)
 {
     if (nrows <= 0) return hipSuccess;
-    const int topw = (int)((((long long)cols + 1023) >> 10) + kRankThreads - 1) / kRankThreads * kRankThreads;   // whole words per thread
+    const long long span = cols < kRankSpan ? cols : kRankSpan;
+    const int topw = (int)(((span + 1023) >> 10) + kRankThreads - 1) / kRankThreads * kRankThreads;   // whole words per thread
     const int bytes = topw * 8 + kRankCap * 4;
-    hipLaunchKernelGGL(k_rank_rows, dim3(nrows), dim3(kRankThreads), bytes, s, ab, Bcol,
-                       (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, topw, rec, recpre, row_begin, tmp, cnt);
+    if (cols > kRankSpan)
+        hipLaunchKernelGGL(k_rank_rows<true>, dim3(nrows), dim3(kRankThreads), bytes, s, ab, Bcol,
+                           (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, topw, rec, recpre, row_begin, tmp, cnt);
+    else
+        hipLaunchKernelGGL(k_rank_rows<false>, dim3(nrows), dim3(kRankThreads), bytes, s, ab, Bcol,
+                           (int)(nnzB > 0x7fffffffll ? 0x7fffffffll : nnzB), cols, topw, rec, recpre, row_begin, tmp, cnt);
     return hipGetLastError();
 }
 

@@ -15,8 +15,8 @@ namespace bsp {
 //                straight-line over its CHUNKS 64-product chunks (exact s_waitcnt counts, no
 //                branches), so a row costs what its CLASS costs: the classes step by one chunk up
 //                to 512 products, by two up to 1024, then by four/eight
-//   kRankBin   : 2048 < F_i <= rank_cap_for_cols(cols) (0 = no such class for this column count): a 512-thread
-//                workgroup with a two-level rank bitmap -- LDS and read-out proportional to the row (dense_rows.hip)
+//   kRankBin   : 2048 < F_i <= rank_cap_for_cols(cols) (0 = no such class for this column count; 6144 for 2^18 < cols <= 2^24):
+//                a 512-thread workgroup with a two-level rank bitmap -- LDS and read-out proportional to the row (dense_rows.hip)
 //   kMidBin    : dense-window rows, up to mid_cap_for_cols(cols) products: 512-thread workgroups, four per CU
 //   kDenseBin  : dense-window rows, above that: one 1024-thread workgroup per row
 constexpr int kWaveBins = 16;

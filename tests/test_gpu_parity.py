@@ -196,12 +196,13 @@ def test_dense_rows_several_windows(ctx):
     assert st["rows_per_bin"][-1] >= 2 and st["rows_per_bin"][-2] >= 1     # both heavy-row shapes, several windows each
 
 
-@pytest.mark.parametrize("ncols", [300_000, 700_001, 1 << 20], ids=["300k_one_top_word_per_thread", "700k", "2pow20"])
+@pytest.mark.parametrize("ncols", [300_000, 700_001, 1 << 20, 3 * (1 << 20) + 777, (1 << 24) - 5],
+                         ids=["300k_one_top_word_per_thread", "700k", "2pow20", "3_spans_and_a_bit", "16_spans"])
 def test_rank_rows_class(ctx, ncols):
     """rows of 2048 < F_i <= 6144 products over two to four windows of the small heavy-row shape take the rank class
-    (csrc/dense_rows.hip k_rank_rows): boundaries of the class, dense column clusters (full 32-column slots, full top
-    words), sources of one to three entries (masked quads), more than 512 sources (several batches) and more than 4096
-    quads (several tiles), repeated A entries, the last column"""
+    (csrc/dense_rows.hip k_rank_rows), on wider matrices in spans of 2^20 columns: boundaries of the class, dense column
+    clusters (full 32-column slots, full top words), sources of one to three entries (masked quads), more than 512 sources
+    (several batches) and more than 4096 quads (several tiles), repeated A entries, the last column"""
     rng = np.random.default_rng(ncols % 1000 + 77)
     nb = 9000
     lens = np.concatenate([rng.integers(1, 4, 6000), rng.integers(4, 200, 2000), rng.integers(200, 1500, 1000)])
@@ -213,8 +214,13 @@ def test_rank_rows_class(ctx, ncols):
             c = np.arange(c0, c0 + L)
         elif kind == 1:    # the tail of the column range, including the last column
             c = ncols - 1 - rng.choice(min(ncols, 4 * L + 8), size=L, replace=False)
+        elif kind == 2 and ncols > (1 << 20):   # around a span boundary
+            c = (1 << 20) * int(rng.integers(1, (ncols >> 20) + 1)) - 2 * L + rng.choice(4 * L, size=L, replace=False)
+            c = c[c < ncols]
+            c = np.concatenate([c, rng.choice(1000, size=L - c.size, replace=False)]) if c.size < L else c
         else:
-            c = rng.choice(ncols, size=L, replace=False)
+            c = rng.permutation(np.unique(rng.integers(0, ncols, size=2 * L)))[:L] if ncols > (1 << 21) else rng.choice(ncols, size=L, replace=False)
+            c = np.concatenate([c, ncols - 1 - np.arange(L - c.size)]) if c.size < L else rng.permutation(c)
         rows.append(np.full(L, j)); cols.append(c)
     b_rp, b_ci = gen._csr_from_pairs(np.concatenate(rows), np.concatenate(cols), nb)
     blen = np.diff(b_rp)

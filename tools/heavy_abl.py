@@ -1,5 +1,5 @@
 """Heavy-row classes timed alone (one class stream), optionally through another build of the library.
-usage: python3 tools/heavy_abl.py <workload: g500|g500_20|powerlaw> [path of libbspgemm.so]
+usage: python3 tools/heavy_abl.py <workload: g500|g500_20|g500_22|powerlaw> [path of libbspgemm.so]
 Timing tool: with an ablated build the RESULT is wrong on purpose; only the class durations mean anything."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,8 @@ if which == "g500":
     rp, ci, n = bspgemm.gen_rmat(18, 16, (0.57, 0.19, 0.19), seed=1)
 elif which == "g500_20":
     rp, ci, n = bspgemm.gen_rmat(20, 8, (0.57, 0.19, 0.19), seed=1)
+elif which == "g500_22":
+    rp, ci, n = bspgemm.gen_rmat(22, 4, (0.57, 0.19, 0.19), seed=1)
 else:
     rp, ci, n = bspgemm.gen_powerlaw(1 << 20, 64, seed=1)
 A = ctx.upload(rp, ci, n)
