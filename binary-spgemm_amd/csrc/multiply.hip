@@ -28,7 +28,7 @@ static bspgemm_status check_operands(bspgemm_context *ctx, const bspgemm_matrix 
 // matrix against ascending capacity: numeric phase 3.74 -> 3.60 ms, step -1.7 %; descending capacity -0.5 %;
 // `profiles/r03_ab_class_order.log`).  Where the heavy classes are a large part of the product the one-wave
 // classes queue behind them and ascending capacity measured better (power-law: +0.8 % otherwise): kept there.
-static void class_order(const int *bin_count, long long total_products, int *order)
+static void class_order(const int *bin_count, long long total_products, int *order, int *lane)
 {
     int light[kWaveBins];                                         // the one-wave classes in launch order
     for (int k = 0; k < kWaveBins; k++) light[k] = k + 1;
@@ -43,18 +43,20 @@ static void class_order(const int *bin_count, long long total_products, int *ord
                 light[c - 1] = t;
             }
     }
-    // the rank class at position 4: with two class streams that is the stream of the small dense shape, not the one of the
-    // hub rows, which ends last where heavy rows matter (power-law stress input: it used to wait 2.5 ms for them)
+    // streams (taken modulo the number in use): the hub rows on 1, the small dense shape on 0 and the rank class behind IT --
+    // the hub rows' stream ends last where heavy rows matter (power-law stress input: the rank class used to wait 2.5 ms for
+    // them) -- and the one-wave classes alternating from 1, as they always did
     order[0] = 0;
+    lane[0] = 0;
     order[1] = kDenseBin;
+    lane[1] = 1;
     order[2] = kMidBin;
-    if (bin_count[kRankBin] > 0) {
-        order[3] = light[0];
-        order[4] = kRankBin;
-        for (int k = 1; k < kWaveBins; k++) order[4 + k] = light[k];
-    } else {                                                      // (no such rows: the one-wave classes alternate over the streams as they always did)
-        for (int k = 0; k < kWaveBins; k++) order[3 + k] = light[k];
-        order[3 + kWaveBins] = kRankBin;
+    lane[2] = 0;
+    order[3] = kRankBin;
+    lane[3] = 0;
+    for (int k = 0; k < kWaveBins; k++) {
+        order[4 + k] = light[k];
+        lane[4 + k] = 3 + k;
     }
     static_assert(kNumBins == kWaveBins + 4, "every class has a position");
 }
@@ -185,16 +187,16 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
     };
 
     // ---- symbolic 2: exact |C_i| of every row, scanned into C.row_ptr -----------------------
-    int order[kNumBins];
+    int order[kNumBins], lane_of[kNumBins] = {};
     if (R > 0) {
-        class_order(h->bin_count, totalF, order);
+        class_order(h->bin_count, totalF, order, lane_of);
         HIPCHK_B(fork(ctx->ev_tile[0][0]));
         for (int pos = 1; pos < kNumBins; pos++) {
             const int b = order[pos];
             const int n = h->bin_count[b];
             cls_n[0][b] = n;
             if (n <= 0) continue;
-            hipStream_t sx = lanes[pos % nlanes];
+            hipStream_t sx = lanes[lane_of[pos] % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[0][b][0], sx));
             if (b <= kWaveBins) {
@@ -248,7 +250,7 @@ static bspgemm_status multiply_exact(bspgemm_context *ctx, const bspgemm_matrix 
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
             // the heavy rows' move runs beside the class launches on the third stream
-            hipStream_t sx = b > kWaveBins ? sC : lanes[pos % nlanes];
+            hipStream_t sx = b > kWaveBins ? sC : lanes[lane_of[pos] % nlanes];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
             if (b <= kWaveBins)
                 launch_wave_rows(b, levels, ctx->ab, Bcol, B->cols, rec, recpre, C->d_row_ptr, n, row_begin,
@@ -359,13 +361,14 @@ static bspgemm_status multiply_upper_bound(bspgemm_context *ctx, const bspgemm_m
         HIPCHK_B(hipEventRecord(ctx->ev_tile[0][0], s));
         for (int l = 1; l < nlanes; l++) HIPCHK_B(hipStreamWaitEvent(lanes[l], ctx->ev_tile[0][0], 0));
         int order[kNumBins];
-        class_order(h->bin_count, h->products, order);
+        int lane_of[kNumBins];
+        class_order(h->bin_count, h->products, order, lane_of);
         for (int pos = 1; pos < kNumBins; pos++) {
             const int b = order[pos];
             const int n = h->bin_count[b];
             cls_n[1][b] = n;
             if (n <= 0) continue;
-            hipStream_t sx = lanes[pos % nlanes];
+            hipStream_t sx = lanes[lane_of[pos] % nlanes];
             const RowRec *rec = ctx->rec + bin_start[b];
             const long long *recpre = ctx->recpre + bin_start[b];
             if (ctx->class_timing) HIPCHK_B(hipEventRecord(slot.ev_cls[1][b][0], sx));
