@@ -817,6 +817,29 @@ def _sampled_rows_exact(rp, ci, n, crp, col_tensor, starts, block=64):
         assert np.array_equal(got, eci), r0
 
 
+def test_row_ranges_with_rank_and_windowed_heavy_rows(ctx):
+    """interior row ranges of a skewed product over 2^19 columns (rank class, two windows of the small shape, the large
+    shape): every range compared completely with the oracle, and the ranges add up to the whole"""
+    rp, ci, n = bspgemm.gen_rmat(19, 3, (0.57, 0.19, 0.19), seed=11)
+    A = ctx.upload(rp, ci, n)
+    whole = ctx.multiply(A, A)
+    st = ctx.stats()
+    B_ = st["bins"]
+    assert st["rows_per_bin"][B_ - 3] > 100 and st["rows_per_bin"][B_ - 2] > 10, st["rows_per_bin"]
+    wrp, wci = whole.download()
+    whole.free()
+    cuts = [0, 1, 777, n // 3 + 5, n - 12345, n]
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        C = ctx.multiply(A, A, r0, r1)
+        crp, cci = C.download()
+        C.free()
+        assert np.array_equal(crp, wrp[r0:r1 + 1] - wrp[r0]), (r0, r1)
+        assert np.array_equal(cci, wci[wrp[r0]:wrp[r1]]), (r0, r1)
+    erp, eci = O.spgemm_rows(rp, ci, rp, ci, n, 0, 4096)      # the heaviest rows of an R-MAT are its first
+    assert np.array_equal(wrp[:4097], erp) and np.array_equal(wci[:wrp[4096]], eci)
+    A.free()
+
+
 def test_baseline_cfg4_rmat_scale24_shards(ctx):
     """BASELINE config 4 shape: R-MAT scale 24 (n = 16.7 M, five-bit levels = 4, nnz(C) = 5.45 G > 2^32),
     multiplied as 8 equal-work row shards like the 8-GPU run; every shard's rows sampled exactly,
