@@ -1,5 +1,5 @@
 """One-off parity campaign beyond tests/: mid-size random products (R-MAT of several skews, power-law,
-uniform, rectangular with hubs) against the CPU oracle, plain and masked.  usage: fuzz_big.py [cases]"""
+uniform, rectangular with hubs) against the CPU oracle, plain and masked.  usage: fuzz_big.py [cases [seed]]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,8 @@ import torch, bspgemm, gen
 from oracle import oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(77)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+rng = np.random.default_rng(seed)
 ctx = bspgemm.Context(0)
 t0 = time.perf_counter()
 for k in range(cases):
@@ -22,20 +23,20 @@ for k in range(cases):
     ctx.set_option("small_path", (-1, 0, 1)[(k // 11) % 3])
     if kind == 0:
         sc = int(rng.integers(12, 17)); abc = [(0.30, 0.25, 0.25), (0.45, 0.22, 0.22), (0.57, 0.19, 0.19)][k // 5 % 3]
-        rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(4, 24)), abc, seed=1000 + k)
+        rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(4, 24)), abc, seed=1000 * (seed - 76) + k)
         b_rp, b_ci, ncols = rp, ci, n
     elif kind == 1:
         n = int(rng.integers(5_000, 120_000))
-        rp, ci, n = bspgemm.gen_powerlaw(n, int(rng.integers(4, 40)), seed=2000 + k)
+        rp, ci, n = bspgemm.gen_powerlaw(n, int(rng.integers(4, 40)), seed=2000 * (seed - 76) + k)
         b_rp, b_ci, ncols = rp, ci, n
     elif kind == 5:
         # round 4: 2^18 < cols <= 2^20 with skew -- rows of 2-6 K products take the rank class (k_rank_rows), larger ones two to four windows
         sc = int(rng.integers(19, 21)); abc = [(0.45, 0.22, 0.22), (0.57, 0.19, 0.19), (0.50, 0.20, 0.20)][k // 6 % 3]
-        rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(2, 5)), abc, seed=5000 + k)
+        rp, ci, n = bspgemm.gen_rmat(sc, int(rng.integers(2, 5)), abc, seed=5000 * (seed - 76) + k)
         b_rp, b_ci, ncols = rp, ci, n
     elif kind == 2:
         n = int(rng.integers(1_000, 300_000))
-        rp, ci, n = bspgemm.gen_uniform(n, int(rng.integers(1, 30)), seed=3000 + k)
+        rp, ci, n = bspgemm.gen_uniform(n, int(rng.integers(1, 30)), seed=3000 * (seed - 76) + k)
         b_rp, b_ci, ncols = rp, ci, n
     else:
         ar, inner = int(rng.integers(100, 20_000)), int(rng.integers(100, 20_000))
