@@ -16,6 +16,7 @@
 #include "kernels.hpp"
 #include "wave.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace bsp {
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
 {
     using LT = GatherLds<kThreads, kQPT>;
     constexpr int kWaves = LT::kWaves, kTileQ = LT::kTileQ, kTileWords = LT::kTileWords;
-    static_assert(kQPT % kInFlight == 0, "whole steps");
+    static_assert(kQPT % kInFlight == 0 && kInFlight % 4 == 0, "whole steps; the last step in quarters");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (a row of several batches -- a hub row has thousands of sources -- loads the extents of batch j+1 while batch j is
     // gathered: one trip to memory less per batch on the row's critical path, and a hub row has the CU to itself)
@@ -157,11 +158,15 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
             const u32 *twb = L.tw[g.buf];
             const int *tpb = L.tpre[g.buf];
             const u32 T0lo = 4u * (u32)T0;
-            for (int k0 = 0; k0 < nqt; k0 += kInFlight * kThreads) {
-                int base[kInFlight];
-                u32 vmask[kInFlight];                              // lanes of the quad that are entries of this source not yet taken
+            // a step takes kInFlight quads per thread; the LAST step of a tile is specialised for the number of slots that still
+            // hold quads for anybody (workgroup-uniform): it is half empty on average, and a row of 3 K products fills 750 of a
+            // step's 2048 quads -- the empty slots used to cost their look-ups and inserts all the same
+            auto step = [&](int k0, auto nu_c) {
+                constexpr int NU = decltype(nu_c)::value;
+                int base[NU];
+                u32 vmask[NU];                                     // lanes of the quad that are entries of this source not yet taken
 #pragma unroll
-                for (int u = 0; u < kInFlight; u++) {
+                for (int u = 0; u < NU; u++) {
                     const int t = k0 + u * kThreads + tid;
                     const bool ok = t < nqt;
                     const int tt = ok ? t : 0;
@@ -177,9 +182,9 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
                     for (int k = 0; k < 4; k++) m |= (ok && b + k >= qs && b + k < sq.y) ? (1u << k) : 0u;
                     vmask[u] = m;
                 }
-                Int4U cv[kInFlight];
+                Int4U cv[NU];
 #pragma unroll
-                for (int u = 0; u < kInFlight; u++) {
+                for (int u = 0; u < NU; u++) {
                     if (nnzB >= 4) {                               // (uniform)
                         cv[u] = *reinterpret_cast<const Int4U *>(Bcol + base[u]);      // only dword aligned
                     } else {                                       // a B of one to three entries: base is 0, no vector load fits
@@ -190,7 +195,14 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kInFlight; u++) ins(cv[u], vmask[u], u);
+                for (int u = 0; u < NU; u++) ins(cv[u], vmask[u], u);
+            };
+            for (int k0 = 0; k0 < nqt; k0 += kInFlight * kThreads) {
+                const int left = nqt - k0;                         // (uniform)
+                if (left > (3 * kInFlight / 4) * kThreads) step(k0, std::integral_constant<int, kInFlight>());
+                else if (left > (kInFlight / 2) * kThreads) step(k0, std::integral_constant<int, 3 * kInFlight / 4>());
+                else if (left > (kInFlight / 4) * kThreads) step(k0, std::integral_constant<int, kInFlight / 2>());
+                else step(k0, std::integral_constant<int, kInFlight / 4>());
             }
         }
         __syncthreads();
@@ -431,6 +443,11 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
     // a row whose quads are one step of the gather keeps them in registers for every later sweep: no plan look-ups, no loads
     Int4U hq[kRankInFlight];
     u32 hm[kRankInFlight];
+#pragma unroll
+    for (int u = 0; u < kRankInFlight; u++) {                      // (slots the gather's last step leaves out stay empty)
+        hq[u].x = hq[u].y = hq[u].z = hq[u].w = 0;
+        hm[u] = 0u;
+    }
     bool held = false;                                             // uniform
     // The column range is taken in SPANS of 2^20 columns (the top bitmap's reach): one for the matrices the class was built
     // for, up to sixteen on wider ones -- where the small dense shape would sweep and read out 4 * sixteen windows.
@@ -495,7 +512,8 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
         };
         if (held) {
 #pragma unroll
-            for (int u = 0; u < kRankInFlight; u++) slot_bits(hq[u], hm[u], u);
+            for (int u = 0; u < kRankInFlight; u++)
+                if ((long long)u * kRankThreads < g.QB) slot_bits(hq[u], hm[u], u);   // (uniform: the slots the gather's one step filled)
             __syncthreads();
         } else {
             gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, false, slot_bits);
