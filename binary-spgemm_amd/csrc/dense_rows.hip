@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
         gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, sp == 0, top_bits);
         if (!kSpans) held = g.plan_kept && g.QB <= kRankInFlight * kRankThreads;   // (only ever used by sweep 2 of the single span)
         // ---- ranks of the top bits: thread t owns the words [t*WPT, (t+1)*WPT) -----------------------------------------
-        int nslots = 0;
+        int nslots = 0, spt = SPT;
         {
             const int WPT = topw / kRankThreads;                   // 1 or 2
             u32 x[2];
@@ -489,12 +489,16 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
                 if (k < wave) off += t;
                 nslots += t;
             }
+            // slots per thread of the read-out: the row's slots spread evenly over the workgroup (a row of 2500 slots: five
+            // per thread on all eight waves, not twelve on the first four)
+            spt = (nslots + kRankThreads - 1) / kRankThreads;
+            spt = spt < 1 ? 1 : (spt > SPT ? SPT : spt);
 #pragma unroll
             for (int k = 0; k < 2; k++)
                 if (k < WPT) {
                     const int pre = off + inc - run + c[k], end = pre + __popc(x[k]);
                     tp[tid * WPT + k].y = (u32)pre;
-                    for (int j = (pre + SPT - 1) / SPT; j * SPT < end && j < kRankThreads; j++) fw[j] = (unsigned short)(tid * WPT + k);   // (at most three)
+                    for (int j = (pre + spt - 1) / spt; j * spt < end && j < kRankThreads; j++) fw[j] = (unsigned short)(tid * WPT + k);   // (the first slot of thread j lies in this word)
                 }
             __syncthreads();
         }
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
         int mine = 0;
 #pragma unroll
         for (int k = 0; k < SPT; k++) {
-            m[k] = S[tid * SPT + k];
+            m[k] = k < spt ? S[tid * spt + k] : 0u;
             mine += __popc(m[k]);
         }
         const int inc = wave_incl_scan(mine);
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
             stotal += t;
         }
         if (nslots > kRankCap) nslots = kRankCap;
-        const int s0 = tid * SPT;
+        const int s0 = tid * spt;
         if (s0 < nslots) {
             int t = fw[tid];
             const uint2 first = tp[t];
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
             for (int skip = s0 - (int)first.y; skip > 0; skip--) rem &= rem - 1u;
 #pragma unroll
             for (int k = 0; k < SPT; k++) {
-                if (s0 + k < nslots) {
+                if (k < spt && s0 + k < nslots) {
                     while (!rem && t + 1 < topw) rem = tp[++t].x;
                     const u32 base = lo + (((u32)t << 10) | ((u32)__builtin_ctz(rem | 0x80000000u) << 5));
                     rem &= rem - 1u;
