@@ -214,9 +214,11 @@ __device__ __forceinline__ void gather_sweep(GatherLds<kThreads, kQPT> &L, Gathe
 // word are neighbours, and the first of each run ORs the whole run -- one LDS atomic per word touched instead of one per
 // product (the dense heads of hub B rows put up to 32 lanes' products into ONE word: same-address atomics serialise).
 // Correct for any order (an unsorted B row only merges less).
+// `windowed`: the entries are filtered by a column window, and a wave whose 64 quads all miss it leaves at once.
 __device__ __forceinline__ void insert_quad(u32 *tgt, bool i0, bool i1, bool i2, bool i3, u32 w0, u32 w1, u32 w2, u32 w3,
-                                            u32 b0, u32 b1, u32 b2, u32 b3)
+                                            u32 b0, u32 b1, u32 b2, u32 b3, bool windowed = false)
 {
+    if (windowed && !__ballot(i0 | i1 | i2 | i3)) return;          // (wave-uniform) nothing of these 64 quads falls into the window
     w0 = i0 ? w0 : 0xfffffff0u, w1 = i1 ? w1 : 0xfffffff1u, w2 = i2 ? w2 : 0xfffffff2u, w3 = i3 ? w3 : 0xfffffff3u;
     const u32 m2 = b2 | (w3 == w2 ? b3 : 0u);
     const u32 m1 = b1 | (w2 == w1 ? m2 : 0u);
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kDenseThreads, (kDenseThreads == kDenseThreadsBig ?
         gather_sweep<kDenseThreads, kQPT, kInFlight>(G, g, ab, Bcol, nnzB, a0, a1, win == 0, [&](const Int4U &v, u32 vm, int) {
             const u32 c0 = (u32)(v.x - lo32), c1 = (u32)(v.y - lo32), c2 = (u32)(v.z - lo32), c3 = (u32)(v.w - lo32);
             insert_quad(bm32, (vm & 1u) && c0 < (u32)W, (vm & 2u) && c1 < (u32)W, (vm & 4u) && c2 < (u32)W, (vm & 8u) && c3 < (u32)W,   // (columns below the window wrap to huge values)
-                        c0 >> 5, c1 >> 5, c2 >> 5, c3 >> 5, 1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
+                        c0 >> 5, c1 >> 5, c2 >> 5, c3 >> 5, 1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31), nwin > 1);
         });
         if (MASKED) {
             // keep the product bits that F's row admits, then wipe P for the next window / row
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
             const u32 c0 = (u32)v.x - lo, c1 = (u32)v.y - lo, c2 = (u32)v.z - lo, c3 = (u32)v.w - lo;   // (columns below the span wrap to huge values)
             insert_quad(tp32, (vm & 1u) && (!kSpans || c0 < (u32)kRankSpan), (vm & 2u) && (!kSpans || c1 < (u32)kRankSpan),
                         (vm & 4u) && (!kSpans || c2 < (u32)kRankSpan), (vm & 8u) && (!kSpans || c3 < (u32)kRankSpan), (c0 >> 10) * 2u, (c1 >> 10) * 2u, (c2 >> 10) * 2u, (c3 >> 10) * 2u,
-                        1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31));
+                        1u << ((c0 >> 5) & 31), 1u << ((c1 >> 5) & 31), 1u << ((c2 >> 5) & 31), 1u << ((c3 >> 5) & 31), kSpans);
         };
         gather_sweep<kRankThreads, kRankQPT, kRankInFlight>(G, g, ab, Bcol, nnzB, a0, a1, sp == 0, top_bits);
         if (!kSpans) held = g.plan_kept && g.QB <= kRankInFlight * kRankThreads;   // (only ever used by sweep 2 of the single span)
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kRankThreads, 8) void k_rank_rows(const int2 *__res
             const u32 r2 = x2.y + __popc(__builtin_amdgcn_ubfe(x2.x, 0u, (c2 >> 5) & 31)), r3 = x3.y + __popc(__builtin_amdgcn_ubfe(x3.x, 0u, (c3 >> 5) & 31));
             // (r < kRankCap always on consistent operands: slots <= F_i <= kRankCap; a rewritten operand is cut off, not LDS overrun)
             insert_quad(S, i0 && r0 < (u32)kRankCap, i1 && r1 < (u32)kRankCap, i2 && r2 < (u32)kRankCap, i3 && r3 < (u32)kRankCap, r0, r1, r2, r3,
-                        1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31));
+                        1u << (c0 & 31), 1u << (c1 & 31), 1u << (c2 & 31), 1u << (c3 & 31), kSpans);
         };
         if (held) {
 #pragma unroll
