@@ -34,7 +34,7 @@ BSPGEMM_FLOW=exact timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no
 echo "stats done"
 for w in "rmat --scale 23" "rmat --scale 24" "uniform" "rmat-g500" "powerlaw"; do
   for f in upper-bound exact; do
-    BSPGEMM_BENCH_NO_DROPIN=1 BSPGEMM_FLOW=$f timeout -k 10 400 python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline >> $OUT/other_$f.jsonl 2>> $OUT/other.err
+    BSPGEMM_BENCH_NO_DROPIN=1 BSPGEMM_FLOW=$f timeout -k 10 400 python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline >> $OUT/other_$f.jsonl 2>> $OUT/other.err
   done
 done
 echo "others done"
