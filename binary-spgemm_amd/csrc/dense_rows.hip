@@ -778,7 +778,11 @@ __global__ __launch_bounds__(256) void k_compact(const int *__restrict__ tmp,
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
                     const int e = 4 * (g0 + 256 * u);
-                    if (e + 3 < n) v[u] = *reinterpret_cast<const Int4U *>(src + o0 + e);     // source only dword aligned
+                    if (e + 3 < n) {                                                          // source only dword aligned
+                        const int *q = src + o0 + e;
+                        v[u].x = __builtin_nontemporal_load(q), v[u].y = __builtin_nontemporal_load(q + 1);
+                        v[u].z = __builtin_nontemporal_load(q + 2), v[u].w = __builtin_nontemporal_load(q + 3);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kU; u++) {
